@@ -1,0 +1,264 @@
+"""CPU tests of the oracle (oracle/orb_oracle.c) against independent re-derivations
+(tests/pyref.py), real implementations present in this container (libstdc++ std::sort,
+glibc sinf/cosf), and the values SURVEY.md section 8 states for the metric config.
+
+The reference holds no test, fixture or golden vector for this path
+(send_slam/test/send_slam_test.exs:5-7 is its only test): parity with the real ORB-SLAM3
+binary is UNPINNED; these tests pin what can be pinned here.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import pyref
+from send_slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_constants_pattern_and_geometry(oracle):
+    # metric config of BASELINE.json / SURVEY.md section 8: 1280x720, 8 levels, 1.2, 2000 kp
+    p = oracle.default_params(n_features=2000)
+    g = oracle.geometry(p, 1280, 720)
+    sizes = [(g.w[l], g.h[l]) for l in range(8)]
+    assert sizes == [(1280, 720), (1067, 600), (889, 500), (741, 417), (617, 347), (514, 289),
+                     (429, 241), (357, 201)]
+    assert sum(w * h for w, h in sizes) == 2853088  # SURVEY.md section 8 header
+    assert sum(list(g.quota)[:8]) == 2000
+    assert list(g.umax) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    # reference literals orbslam3_mono_networked.cc:193-206
+    d = oracle.default_params()
+    assert (d.n_features, d.n_levels, d.ini_th_fast, d.min_th_fast) == (1250, 8, 20, 7)
+    assert abs(d.scale_factor - 1.2) < 1e-6
+    for wh, px in (((640, 480), 950532), ((1920, 1080), 6419321)):
+        gg = oracle.geometry(p, *wh)
+        assert sum(gg.w[l] * gg.h[l] for l in range(8)) == px
+
+
+def test_std_sort_restatement_matches_libstdcxx(tmp_path, oracle):
+    exe = str(tmp_path / "std_sort_pin")
+    subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "tests/native/std_sort_pin.cpp"),
+                           "-L" + os.path.join(ROOT, "oracle"), "-lorb_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches=0" in out.stdout
+
+
+@pytest.mark.parametrize("shape", [(97, 131), (240, 320), (201, 357)])
+def test_resize_matches_numpy_rederivation(oracle, shape):
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    dh, dw = int(round(shape[0] / 1.2)), int(round(shape[1] / 1.2))
+    got = oracle.resize_linear(src, dw, dh)
+    assert np.array_equal(got, pyref.resize_linear(src, dw, dh))
+    flat = np.full(shape, 77, np.uint8)
+    assert (oracle.resize_linear(flat, dw, dh) == 77).all()
+
+
+def test_fast_score_map_matches_arc_definition(oracle):
+    img = synth.frame(3, 160, 120)
+    r = pyref.fast_response(img)
+    for t in (7, 20):
+        got = oracle.fast_score_map(img, t)
+        assert np.array_equal(got, pyref.fast_score_map(img, t))
+    # threshold independence used by the device response map: score(t) == R-1 wherever R > t
+    s7, s20 = oracle.fast_score_map(img, 7), oracle.fast_score_map(img, 20)
+    assert np.array_equal(np.where(s7 >= 20, s7, 0), s20)
+    assert (r > 20).sum() > 50
+
+
+def _cell_candidates_from_map(img, ini_th, min_th):
+    """K3 restated on the whole-image response map: the device formulation."""
+    h, w = img.shape
+    r = pyref.fast_response(img)
+    score = np.where(r > min_th, r - 1, 0)
+    width, height = np.float32(w - 32), np.float32(h - 32)
+    n_cols, n_rows = int(width / np.float32(35)), int(height / np.float32(35))
+    w_cell, h_cell = int(np.ceil(width / n_cols)), int(np.ceil(height / n_rows))
+    max_bx, max_by = w - 16, h - 16
+    out = []
+    for i in range(n_rows):
+        ini_y = 16 + i * h_cell
+        max_y = min(ini_y + h_cell + 6, max_by)
+        if ini_y >= max_by - 3:
+            continue
+        for j in range(n_cols):
+            ini_x = 16 + j * w_cell
+            max_x = min(ini_x + w_cell + 6, max_bx)
+            if ini_x >= max_bx - 6:
+                continue
+            for th in (ini_th, min_th):
+                sub = np.zeros((max_y - ini_y, max_x - ini_x), np.int64)
+                sub[3:-3, 3:-3] = score[ini_y + 3:max_y - 3, ini_x + 3:max_x - 3]
+                sub = np.where(sub >= th, sub, 0)
+                found = []
+                for y in range(3, sub.shape[0] - 3):
+                    for x in range(3, sub.shape[1] - 3):
+                        s = sub[y, x]
+                        if s == 0:
+                            continue
+                        nb = sub[y - 1:y + 2, x - 1:x + 2].copy()
+                        nb[1, 1] = -1
+                        if (s > nb).all():
+                            found.append((x + j * w_cell, y + i * h_cell, int(s)))
+                if found:
+                    break
+            out.extend(found)
+    return out
+
+
+def test_candidates_match_response_map_formulation(oracle):
+    img = synth.frame(5, 200, 150)
+    got = oracle.candidates(img, 20, 7)
+    want = _cell_candidates_from_map(img, 20, 7)
+    assert [(int(a["x"]), int(a["y"]), int(a["response"])) for a in got] == want
+    assert len(want) > 30
+    # low-contrast image: cells fall back to minThFAST
+    low = (img.astype(np.int32) // 6 + 100).astype(np.uint8)
+    got = oracle.candidates(low, 20, 7)
+    want = _cell_candidates_from_map(low, 20, 7)
+    assert [(int(a["x"]), int(a["y"]), int(a["response"])) for a in got] == want
+    assert len(want) > 0 and min(w[2] for w in want) < 20
+
+
+@pytest.mark.parametrize("seed,wh,n", [(0, (320, 240), 60), (1, (320, 240), 10), (2, (400, 200), 150),
+                                       (3, (357, 201), 122), (4, (320, 240), 1), (5, (320, 240), 5000)])
+def test_quadtree_list_form_equals_array_form(oracle, seed, wh, n):
+    img = synth.frame(seed, *wh)
+    cand = oracle.candidates(img, 20, 7)
+    got = oracle.distribute(cand, wh[0], wh[1], n)
+    tup = [(int(c["x"]), int(c["y"]), int(c["response"])) for c in cand]
+    want = pyref.distribute_array_form(tup, wh[0], wh[1], n, oracle.std_sort)
+    assert [(int(a["x"]), int(a["y"]), int(a["response"])) for a in got] == want
+    assert len(want) <= max(n + 3, 8)
+    assert set(want) <= set(tup)
+    if n < len(tup) // 2:
+        assert len(want) >= n
+
+
+def test_fast_atan2_accuracy_and_octants(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = float(rng.integers(-200000, 200000)), float(rng.integers(-200000, 200000))
+        if x == 0 and y == 0:
+            continue
+        a = oracle.fast_atan2(y, x)
+        ref = pyref.fast_atan2_deg(y, x)
+        diff = abs(a - ref)
+        assert min(diff, 360 - diff) < 0.3
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    assert oracle.fast_atan2(0.0, 5.0) == 0.0
+    assert abs(oracle.fast_atan2(5.0, 0.0) - 90.0) < 1e-3
+    assert abs(oracle.fast_atan2(0.0, -5.0) - 180.0) < 1e-3
+
+
+def test_ic_angle_moments(oracle):
+    img = synth.frame(7, 160, 120)
+    p = oracle.default_params()
+    umax = list(oracle.geometry(p, 640, 480).umax)
+    for (x, y) in [(40, 40), (100, 60), (120, 90)]:
+        m01 = m10 = 0
+        for v in range(-15, 16):
+            d = umax[abs(v)]
+            for u in range(-d, d + 1):
+                val = int(img[y + v, x + u])
+                m10 += u * val
+                m01 += v * val
+        assert oracle.ic_angle(img, x, y, umax) == oracle.fast_atan2(float(m01), float(m10))
+
+
+def test_blur_matches_numpy_rederivation(oracle):
+    assert int(pyref.GAUSS.sum()) == 256
+    img = synth.frame(9, 150, 110)
+    assert np.array_equal(oracle.blur(img), pyref.blur(img))
+    flat = np.full((40, 50), 201, np.uint8)
+    assert (oracle.blur(flat) == 201).all()
+    tiny = np.arange(7 * 9, dtype=np.uint8).reshape(7, 9)
+    assert np.array_equal(oracle.blur(tiny), pyref.blur(tiny))
+
+
+def test_descriptor_bits(oracle):
+    img = oracle.blur(synth.frame(11, 160, 120))
+    pat = np.array(pyref.parse_c_int_table(os.path.join(ROOT, "oracle/orb_constants.h"),
+                                           "ORC_BIT_PATTERN_31"), np.int64).reshape(256, 4)
+    assert np.abs(pat).max() == 13
+    for (x, y, ang) in [(60, 50, 0.0), (80, 70, 33.3), (100, 60, 181.25), (70, 90, 359.9)]:
+        got = oracle.descriptor(img, x, y, ang)
+        f = np.float32(np.float64(np.pi) / np.float32(180.0))
+        rad = np.float32(ang) * f
+        a = np.cos(np.float64(rad)).astype(np.float32)  # close enough to cosf to place taps:
+        b = np.sin(np.float64(rad)).astype(np.float32)  # a tap that differs would show as a bit diff
+        bits = []
+        for (x0, y0, x1, y1) in pat:
+            def tap(px, py):
+                yy = int(np.rint(np.float32(np.float32(px) * b) + np.float32(np.float32(py) * a)))
+                xx = int(np.rint(np.float32(np.float32(px) * a) - np.float32(np.float32(py) * b)))
+                return int(img[y + yy, x + xx])
+            bits.append(1 if tap(x0, y0) < tap(x1, y1) else 0)
+        want = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert (np.unpackbits(got ^ want).sum()) <= 1  # <= 1 bit: cosf vs cos(double) 1-ulp taps
+
+
+def test_match_matches_numpy(oracle):
+    rng = np.random.default_rng(4)
+    q = rng.integers(0, 256, size=(70, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(90, 32), dtype=np.uint8)
+    t[10] = q[3]
+    t[11] = q[3]  # exact duplicate: tie -> lowest index, d2 == d1 == 0 -> rejected by ratio
+    t[40] = q[5]
+    t[40, 7] ^= 1
+    for kw in (dict(th=50), dict(th=100, ratio_num=7), dict(th=256, ratio_num=10)):
+        a = oracle.match(q, t, **kw)
+        b = pyref.match(q, t, kw.get("th", 50), kw.get("ratio_num", 9), 10)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    idx, d1, d2 = oracle.match(q, t, th=50)
+    assert idx[3] == -1 and d1[3] == 0 and d2[3] == 0
+    assert idx[5] == 40 and d1[5] == 1
+    # self-match excludes j == i
+    a = oracle.match(q, q, th=256, ratio_num=10, exclude_self=True)
+    b = pyref.match(q, q, 256, 10, 10, exclude_self=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert (a[0] != np.arange(70)).all()
+    # empty and single-element train sets
+    idx, d1, d2 = oracle.match(q, t[:0])
+    assert (idx == -1).all() and (d1 == 0xFFFF).all()
+    idx, d1, d2 = oracle.match(q[:2], t[10:11], th=256)
+    assert d2[0] == 0xFFFF
+
+
+def test_gray_fixed_point(oracle):
+    rng = np.random.default_rng(2)
+    src = rng.integers(0, 256, size=(20, 30, 3), dtype=np.uint8)
+    s = src.astype(np.int64)
+    for rgb in (0, 1):
+        c = (9798, 19235, 3735) if rgb else (3735, 19235, 9798)
+        want = ((s[..., 0] * c[0] + s[..., 1] * c[1] + s[..., 2] * c[2] + 16384) >> 15).astype(np.uint8)
+        assert np.array_equal(oracle.gray(src, rgb), want)
+    white = np.full((4, 4, 3), 255, np.uint8)
+    assert (oracle.gray(white, 1) == 255).all()
+
+
+def test_extract_counts_order_and_lapping(oracle):
+    img = synth.frame(0, 640, 480)
+    p = oracle.default_params()  # 1250 features: config 1 of BASELINE.json
+    kps, desc, counts = oracle.extract(img, p)
+    g = oracle.geometry(p, 640, 480)
+    assert len(kps) == counts.sum() and desc.shape == (len(kps), 32)
+    assert all(counts[l] <= max(g.quota[l] + 3, 8) for l in range(8))
+    assert counts.sum() >= 1200  # the synthetic scene saturates the quotas
+    # lapping area {0, 1000}: at 640 px wide every keypoint is "stereo" -> filled from the back,
+    # so the level-major order appears reversed
+    assert list(kps["octave"]) == sorted(kps["octave"], reverse=True)
+    # with an empty lapping area the order is level-major from the front
+    p2 = oracle.default_params(lapping_x0=-2, lapping_x1=-1)
+    k2, d2, _ = oracle.extract(img, p2)
+    assert np.array_equal(k2[::-1], kps) and np.array_equal(d2[::-1], desc)
+    # keypoints stay >= 19 px (EDGE_THRESHOLD) inside their level
+    lx = kps["x"] / np.array([g.scale[o] for o in kps["octave"]], np.float32)
+    assert lx.min() >= 18.99
