@@ -1,0 +1,185 @@
+/*
+ * sendslam_orb.h -- C ABI of libsendslam_orb.so: the MI355X-native ORB tracking front-end
+ * that replaces SEND-SLAM's dockerised ORB-SLAM3 CPU backend for ONE path: per-frame ORB
+ * extraction (pyramid, FAST-9 + NMS, quadtree distribution, orientation, rBRIEF) and
+ * brute-force Hamming matching with a ratio test.
+ *
+ * Plain C linkage, plain pointers and sizes, int status (0 = ok, < 0 = ss_status), no
+ * exception crosses.  What each entry point replaces in the reference
+ * (/root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc unless noted):
+ *
+ *   ss_create / ss_destroy     make_unique<ORB_SLAM3::System>(voc, yaml, MONOCULAR, false) :511,
+ *                              Shutdown :654; ORB parameters = the YAML literals :193-206
+ *   ss_set_calibration         the "calibration" message branch :477-519 with the 16 scalars of
+ *                              CameraCalibration :59-77 / ParseCameraCalibration :109-137
+ *   ss_extract                 the "frame" branch :521-627 up to and inside TrackMonocular :594
+ *                              (ORBextractor::operator()), pixels as cv::imdecode leaves them :546
+ *   ss_extract_batch_device    same, for a batch of frames already resident in HBM (cameras /
+ *                              frame batches shard one per GPU; no counterpart in the reference,
+ *                              which handles one camera on one thread :594)
+ *   ss_match*                  ORBmatcher::DescriptorDistance + best/second-best search inside
+ *                              TrackMonocular :594 (all-pairs rule: SURVEY.md Appendix A.6)
+ *   ss_stats                   vTimesTrack median/mean summary :615-616, :656-664
+ *   ss_last_error              the cerr diagnostics of the shim (:457-469, :523-551)
+ *
+ * Threading: a context is single-threaded (one HIP stream, one camera or one batch in
+ * flight); distinct contexts are independent and may live on different devices.  A call
+ * that fails leaves the context usable (the shim's log-and-skip policy, :523-551).
+ * Every entry point takes longer than 1 ms on first use: NIF callers flag them dirty
+ * (INTEGRATION.md).
+ *
+ * The library has NO CPU fallback: without a usable HIP device ss_create fails with
+ * SS_ERR_NO_DEVICE.
+ */
+#ifndef SENDSLAM_ORB_H
+#define SENDSLAM_ORB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+#define SS_MAX_LEVELS 16
+#define SS_DESC_BYTES 32
+
+typedef enum {
+    SS_OK = 0,
+    SS_ERR_INVALID_ARG = -1,
+    SS_ERR_NO_DEVICE = -2,
+    SS_ERR_HIP = -3,
+    SS_ERR_TOO_SMALL = -4,      /* image too small for the cell grid at some level */
+    SS_ERR_OVERFLOW = -5,       /* an internal capacity was exceeded; nothing was truncated */
+    SS_ERR_NOT_CALIBRATED = -6, /* frame before calibration (shim :523-527) */
+    SS_ERR_BAD_FRAME = -7,
+    SS_ERR_NO_MEMORY = -8,
+    SS_ERR_STATE = -9
+} ss_status;
+
+typedef struct ss_ctx ss_ctx;
+
+/* ORB parameters.  Defaults are the reference's YAML literals (:193-206): 1250 features,
+ * scale 1.2, 8 levels, FAST 20 / 7; lapping area {0, 1000} is ORB-SLAM3's monocular
+ * Frame constructor (ExtractORB(0, im, 0, 1000)). */
+typedef struct {
+    int32_t n_features;
+    float scale_factor;
+    int32_t n_levels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t lapping_x0;
+    int32_t lapping_x1;
+    int32_t max_batch; /* frames per ss_extract_batch_device call; >= 1 */
+} ss_orb_params;
+
+/* The 16 calibration scalars of the wire protocol (shim :59-77; produced by
+ * send_slam/lib/send_slam/slam_handler.ex:209-226). */
+typedef struct {
+    char type[16]; /* "PinHole" */
+    double fx, fy, cx, cy;
+    double k1, k2, p1, p2;
+    int32_t width, height;
+    double fps;
+    int32_t rgb; /* Camera.RGB: 1 = byte 0 of a 3-channel pixel is treated as R */
+    double th_depth, baseline, depth_map_factor;
+} ss_camera;
+
+/* cv::KeyPoint fields the extractor fills */
+typedef struct {
+    float x, y;     /* level-0 pixel coordinates */
+    float size;     /* (int)(31 * scale^octave) */
+    float angle;    /* degrees [0, 360) */
+    float response; /* FAST score */
+    int32_t octave;
+} ss_keypoint;
+
+/* Result of ss_extract: host arrays owned by the context, valid until the next call on it */
+typedef struct {
+    int32_t n_keypoints;
+    int32_t camera_id;
+    double timestamp;
+    const ss_keypoint *keypoints; /* n_keypoints */
+    const uint8_t *descriptors;   /* n_keypoints x 32, row-major (CV_8U N x 32) */
+    int32_t level_counts[SS_MAX_LEVELS];
+} ss_frame_result;
+
+/* Device-resident results of the last ss_extract_batch_device call */
+typedef struct {
+    int32_t n_frames;
+    int32_t kp_capacity;           /* rows per frame in the two arrays below */
+    const ss_keypoint *keypoints;  /* device: [n_frames][kp_capacity] */
+    const uint8_t *descriptors;    /* device: [n_frames][kp_capacity][32] */
+    const int32_t *n_keypoints;    /* device: [n_frames] */
+    const int32_t *level_counts;   /* device: [n_frames][SS_MAX_LEVELS] */
+} ss_batch_view;
+
+typedef struct {
+    char name[32];
+    int64_t launches;
+    double total_ms;  /* HIP-event time on the context's stream */
+    double mean_ms;   /* per launch */
+    double median_ms; /* per launch */
+    int64_t algorithmic_bytes; /* per launch of the last shape run */
+} ss_stage_stats;
+
+int ss_abi_version(void);
+int ss_orb_params_default(ss_orb_params *p);
+
+int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out);
+int ss_destroy(ss_ctx *ctx);
+/* ctx may be NULL: returns the message of the last failed ss_create on this thread */
+const char *ss_last_error(const ss_ctx *ctx);
+
+int ss_set_calibration(ss_ctx *ctx, int camera_id, const ss_camera *cam);
+
+/* Host pixels in, host keypoints/descriptors out; synchronous.  channels 1 (gray), 3 or 4
+ * (converted with the calibration's rgb flag, exactly as GrabImageMonocular does);
+ * camera_id must be non-zero (shim :528); caller keeps ownership of pix. */
+int ss_extract(ss_ctx *ctx, int camera_id, const uint8_t *pix, int width, int height,
+               int channels, int row_stride, double timestamp, ss_frame_result *out);
+
+/* n_frames <= max_batch frames already in device memory (row_stride / frame_stride in
+ * bytes).  Asynchronous on the context's stream; results stay on the device. */
+int ss_extract_batch_device(ss_ctx *ctx, const void *d_pix, int n_frames, int width,
+                            int height, int channels, int64_t row_stride,
+                            int64_t frame_stride);
+int ss_get_batch_view(ss_ctx *ctx, ss_batch_view *out);
+
+/* K7.  idx[i] = index of the accepted best train descriptor or -1; d1/d2 = best and
+ * second-best distance (0xFFFF when absent).  Accept iff d1 <= th and d1*ratio_den <
+ * d2*ratio_num.  exclude_self skips j == i.  Ties: lowest index. */
+int ss_match(ss_ctx *ctx, const uint8_t *query, int n_query, const uint8_t *train,
+             int n_train, int th, int ratio_num, int ratio_den, int exclude_self,
+             int32_t *idx, uint16_t *d1, uint16_t *d2);
+/* same with device pointers, asynchronous on the context's stream */
+int ss_match_device(ss_ctx *ctx, const void *d_query, int n_query, const void *d_train,
+                    int n_train, int th, int ratio_num, int ratio_den, int exclude_self,
+                    void *d_idx, void *d_d1, void *d_d2);
+/* Matches every frame of the last batch: mode 0 = self-match (exclude j == i), mode 1 =
+ * frame b against frame b-1 (frame 0 against itself, excluding j == i).  Outputs are
+ * device arrays [n_frames][kp_capacity]; rows >= n_keypoints[b] are idx -1. */
+int ss_match_batch_device(ss_ctx *ctx, int mode, int th, int ratio_num, int ratio_den,
+                          void *d_idx, void *d_d1, void *d_d2);
+
+int ss_synchronize(ss_ctx *ctx);
+/* the hipStream_t every kernel of this context is launched on */
+int ss_get_stream(ss_ctx *ctx, void **hip_stream);
+
+/* Per-kernel HIP-event timing on the context's stream (off by default). */
+int ss_profile_enable(ss_ctx *ctx, int on);
+int ss_profile_reset(ss_ctx *ctx);
+/* fills up to max_stages entries, returns the number of stages (or < 0) */
+int ss_stats(ss_ctx *ctx, ss_stage_stats *out, int max_stages);
+
+/* Intermediate buffers of the last batch, for stage-by-stage parity tests.  what:
+ * 0 pyramid level, 1 blurred level, 2 FAST score map (tight w*h u8 each); 3 candidates,
+ * 4 quadtree-selected keypoints of a level (int32 triples x, y, response; candidates are
+ * relative to the (16,16) border origin, selected are level coordinates).  Returns the
+ * number of bytes written to dst (<= dst_bytes) or < 0. */
+int ss_debug_fetch(ss_ctx *ctx, int what, int frame, int level, void *dst, int64_t dst_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,647 @@
+/*
+ * ss_api.cpp -- the C ABI of libsendslam_orb.so (include/sendslam_orb.h): context, HBM
+ * buffers, the per-batch kernel sequence on ONE HIP stream, HIP-event stage timing.
+ *
+ * Host-side counterpart of the reference shim's frame branch
+ * (/root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc:521-627): same
+ * guards and the same log-and-skip error policy, with the ORB-SLAM3 call at :594 replaced
+ * by the kernel sequence below.  No CPU fallback exists: every stage runs on the device.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sendslam_orb.h"
+#include "ss_constants.h"
+#include "ss_geometry.h"
+#include "ss_kernels.h"
+#include "ss_layout.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct stage_rec {
+    std::string name;
+    int64_t bytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<float> ms;
+};
+
+template <typename T> void dev_free(T *&p)
+{
+    if (p) (void)hipFree((void *)p);
+    p = nullptr;
+}
+
+} // namespace
+
+struct ss_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ss_orb_params params{};
+    std::string err;
+    bool calibrated = false;
+    ss_camera cam{};
+    int cam_id = 0;
+
+    bool have_geom = false;
+    ss_geom hg{};
+    ss_host_tables tabs;
+    ss_geom *dg = nullptr;
+    ss_rtab *d_rtab = nullptr;
+    uint32_t *d_tiles = nullptr;
+
+    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr;
+    int32_t *cell_cnt = nullptr;
+    uint32_t *cand = nullptr, *qbuf0 = nullptr, *qbuf1 = nullptr;
+    ss_qnode *nodes = nullptr;
+    int32_t *lists = nullptr;
+    uint32_t *sel = nullptr;
+    ss_level_state *state = nullptr;
+    uint32_t *kp_ref = nullptr;
+    int32_t *n_kp = nullptr, *level_counts = nullptr, *frame_error = nullptr;
+    ss_keypoint *kps = nullptr;
+    uint8_t *desc = nullptr;
+
+    uint8_t *d_in = nullptr;
+    size_t d_in_bytes = 0;
+    void *match_partial = nullptr;
+    size_t match_partial_bytes = 0;
+    uint8_t *d_mq = nullptr, *d_mt = nullptr, *d_mout = nullptr;
+    size_t d_mq_bytes = 0, d_mt_bytes = 0, d_mout_bytes = 0;
+
+    /* host results of ss_extract */
+    std::vector<ss_keypoint> h_kps;
+    std::vector<uint8_t> h_desc;
+    std::vector<int32_t> h_err;
+
+    int last_n_frames = 0;
+
+    bool profile = false;
+    std::vector<stage_rec> stages;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(ss_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((c), e_ == hipErrorOutOfMemory ? SS_ERR_NO_MEMORY : SS_ERR_HIP,       \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+stage_rec &stage(ss_ctx *c, const char *name)
+{
+    for (auto &s : c->stages)
+        if (s.name == name) return s;
+    c->stages.emplace_back();
+    c->stages.back().name = name;
+    return c->stages.back();
+}
+
+hipEvent_t get_event(ss_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct stage_timer {
+    ss_ctx *c;
+    stage_rec *s = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    stage_timer(ss_ctx *ctx, const char *name, int64_t bytes) : c(ctx)
+    {
+        if (!c->profile) return;
+        s = &stage(c, name);
+        s->bytes = bytes;
+        a = get_event(c);
+        b = get_event(c);
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~stage_timer()
+    {
+        if (!s) return;
+        (void)hipEventRecord(b, c->stream);
+        s->pending.emplace_back(a, b);
+    }
+};
+
+void collect_events(ss_ctx *c)
+{
+    for (auto &s : c->stages) {
+        for (auto &p : s.pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) s.ms.push_back(ms);
+            c->event_pool.push_back(p.first);
+            c->event_pool.push_back(p.second);
+        }
+        s.pending.clear();
+    }
+}
+
+void free_geometry_buffers(ss_ctx *c)
+{
+    dev_free(c->dg);
+    dev_free(c->d_rtab);
+    dev_free(c->d_tiles);
+    dev_free(c->pyr);
+    dev_free(c->blur);
+    dev_free(c->score);
+    dev_free(c->cell_cnt);
+    dev_free(c->cand);
+    dev_free(c->qbuf0);
+    dev_free(c->qbuf1);
+    dev_free(c->nodes);
+    dev_free(c->lists);
+    dev_free(c->sel);
+    dev_free(c->state);
+    dev_free(c->kp_ref);
+    dev_free(c->n_kp);
+    dev_free(c->level_counts);
+    dev_free(c->frame_error);
+    dev_free(c->kps);
+    dev_free(c->desc);
+    c->have_geom = false;
+}
+
+int ensure_geometry(ss_ctx *c, int w, int h)
+{
+    if (c->have_geom && c->hg.w == w && c->hg.h == h) return SS_OK;
+    (void)hipStreamSynchronize(c->stream);
+    free_geometry_buffers(c);
+    std::string msg;
+    ss_geom g;
+    int rc = ss_build_geometry(c->params, w, h, &g, &c->tabs, &msg);
+    if (rc != SS_OK) return fail(c, rc, msg);
+    for (int l = 0; l < g.n_levels; l++)
+        if (g.lv[l].item_cap > 4096)
+            return fail(c, SS_ERR_INVALID_ARG, "n_features too large: per-level quota exceeds 4080");
+    c->hg = g;
+    const size_t B = (size_t)c->params.max_batch;
+    HIP_TRY(c, hipMalloc((void **)&c->dg, sizeof(ss_geom)));
+    HIP_TRY(c, hipMemcpy(c->dg, &g, sizeof(ss_geom), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->d_rtab, std::max<size_t>(c->tabs.rtab.size(), 1) * sizeof(ss_rtab)));
+    if (!c->tabs.rtab.empty())
+        HIP_TRY(c, hipMemcpy(c->d_rtab, c->tabs.rtab.data(), c->tabs.rtab.size() * sizeof(ss_rtab), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tiles, c->tabs.tiles.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_tiles, c->tabs.tiles.data(), c->tabs.tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->score, B * g.block_bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->cell_cnt, B * g.n_cells * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->cand, B * g.cand_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->qbuf0, B * g.cand_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->qbuf1, B * g.cand_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->nodes, B * g.node_total * sizeof(ss_qnode)));
+    HIP_TRY(c, hipMalloc((void **)&c->lists, B * g.item_total * 2 * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->sel, B * g.sel_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->state, B * SS_MAX_LEVELS * sizeof(ss_level_state)));
+    HIP_TRY(c, hipMalloc((void **)&c->kp_ref, B * g.kcap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->n_kp, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->level_counts, B * SS_MAX_LEVELS * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->frame_error, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->kps, B * g.kcap * sizeof(ss_keypoint)));
+    HIP_TRY(c, hipMalloc((void **)&c->desc, B * g.kcap * SS_DESC_BYTES));
+    HIP_TRY(c, hipMemset(c->n_kp, 0, B * sizeof(int32_t)));
+    HIP_TRY(c, hipMemset(c->kps, 0, B * g.kcap * sizeof(ss_keypoint)));
+    HIP_TRY(c, hipMemset(c->desc, 0, B * g.kcap * SS_DESC_BYTES));
+    c->have_geom = true;
+    c->last_n_frames = 0;
+    return SS_OK;
+}
+
+int64_t level_px(const ss_geom &g, int l) { return (int64_t)g.lv[l].w * g.lv[l].h; }
+
+/* the per-batch kernel sequence; d_pix is device memory */
+int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_stride, int64_t frame_stride)
+{
+    const ss_geom &g = c->hg;
+    hipStream_t s = c->stream;
+    int64_t all_px = 0;
+    for (int l = 0; l < g.n_levels; l++) all_px += level_px(g, l);
+
+    HIP_TRY(c, hipMemsetAsync(c->state, 0, (size_t)n * SS_MAX_LEVELS * sizeof(ss_level_state), s));
+    {
+        int c0 = 0, c1 = 0, c2 = 0;
+        if (channels != 1) { /* Camera.RGB: 1 -> byte 0 weighs as R */
+            const bool rgb = c->calibrated ? c->cam.rgb != 0 : false;
+            c0 = rgb ? SS_GRAY_RY : SS_GRAY_BY;
+            c1 = SS_GRAY_GY;
+            c2 = rgb ? SS_GRAY_BY : SS_GRAY_RY;
+        }
+        stage_timer t(c, "ingest", n * level_px(g, 0) * (channels + 1));
+        ssk_ingest(s, d_pix, channels, row_stride, frame_stride, c0, c1, c2, c->pyr, c->dg, g, n);
+    }
+    for (int l = 1; l < g.n_levels; l++) {
+        stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
+        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
+    }
+    {
+        stage_timer t(c, "fast_score", n * all_px);
+        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles, n);
+    }
+    {
+        stage_timer t(c, "blur", n * 2 * all_px);
+        ssk_blur(s, c->pyr, c->blur, c->dg, g, c->d_tiles, n);
+    }
+    {
+        stage_timer t(c, "cells_count", n * all_px);
+        ssk_cells(s, false, c->score, c->dg, g, c->cell_cnt, c->cand, c->state, n);
+    }
+    {
+        stage_timer t(c, "cells_emit", n * all_px);
+        ssk_cells(s, true, c->score, c->dg, g, c->cell_cnt, c->cand, c->state, n);
+    }
+    {
+        stage_timer t(c, "quadtree", 0);
+        ssk_quadtree(s, c->dg, g, c->cand, c->qbuf0, c->qbuf1, c->nodes, c->lists, c->sel, c->state, n);
+    }
+    {
+        stage_timer t(c, "slots", 0);
+        ssk_slots(s, c->dg, c->sel, c->state, c->kp_ref, c->n_kp, c->level_counts, c->frame_error, n);
+    }
+    {
+        stage_timer t(c, "orient_describe", (int64_t)n * g.n_features * (709 + 512 + 32 + 24));
+        ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->last_n_frames = n;
+    return SS_OK;
+}
+
+int check_frame_errors(ss_ctx *c)
+{
+    const int n = c->last_n_frames;
+    if (n <= 0) return SS_OK;
+    c->h_err.resize((size_t)n);
+    HIP_TRY(c, hipMemcpyAsync(c->h_err.data(), c->frame_error, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++)
+        if (c->h_err[i] != 0)
+            return fail(c, SS_ERR_OVERFLOW, "frame " + std::to_string(i) + ": an internal capacity was exceeded (code " +
+                                                std::to_string(c->h_err[i]) + "); no result was truncated");
+    return SS_OK;
+}
+
+template <typename T> int grow(ss_ctx *c, T *&p, size_t &have, size_t want)
+{
+    if (have >= want) return SS_OK;
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(p);
+    have = 0;
+    HIP_TRY(c, hipMalloc((void **)&p, want));
+    have = want;
+    return SS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+int ss_orb_params_default(ss_orb_params *p)
+{
+    if (!p) return SS_ERR_INVALID_ARG;
+    p->n_features = SS_DEFAULT_NFEATURES;
+    p->scale_factor = SS_DEFAULT_SCALE;
+    p->n_levels = SS_DEFAULT_NLEVELS;
+    p->ini_th_fast = SS_DEFAULT_INI_TH;
+    p->min_th_fast = SS_DEFAULT_MIN_TH;
+    p->lapping_x0 = SS_DEFAULT_LAPPING_X0;
+    p->lapping_x1 = SS_DEFAULT_LAPPING_X1;
+    p->max_batch = 1;
+    return SS_OK;
+}
+
+int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
+{
+    if (!out) return fail(nullptr, SS_ERR_INVALID_ARG, "ss_create: out is NULL");
+    *out = nullptr;
+    ss_orb_params p;
+    ss_orb_params_default(&p);
+    if (params) p = *params;
+    if (p.max_batch < 1 || p.max_batch > 4096) return fail(nullptr, SS_ERR_INVALID_ARG, "max_batch out of range (1..4096)");
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, SS_ERR_NO_DEVICE,
+                    std::string("no HIP device: this library has no CPU path (") + hipGetErrorString(e) + ")");
+    if (device_ordinal < 0 || device_ordinal >= n_dev)
+        return fail(nullptr, SS_ERR_NO_DEVICE, "device ordinal " + std::to_string(device_ordinal) + " out of range");
+    HIP_TRY((ss_ctx *)nullptr, hipSetDevice(device_ordinal));
+    {
+        /* validate the parameters on a nominal size now, so a bad parameter fails here */
+        ss_geom g;
+        ss_host_tables tabs;
+        std::string msg;
+        int rc = ss_build_geometry(p, 640, 480, &g, &tabs, &msg);
+        if (rc == SS_ERR_INVALID_ARG) return fail(nullptr, rc, msg);
+    }
+    ss_ctx *c = new ss_ctx();
+    c->device = device_ordinal;
+    c->params = p;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete c;
+        return fail(nullptr, SS_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se));
+    }
+    *out = c;
+    return SS_OK;
+}
+
+int ss_destroy(ss_ctx *c)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_events(c);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    free_geometry_buffers(c);
+    dev_free(c->d_in);
+    dev_free(c->match_partial);
+    dev_free(c->d_mq);
+    dev_free(c->d_mt);
+    dev_free(c->d_mout);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SS_OK;
+}
+
+const char *ss_last_error(const ss_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ss_set_calibration(ss_ctx *c, int camera_id, const ss_camera *cam)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    if (camera_id == 0) return fail(c, SS_ERR_INVALID_ARG, "Calibration message missing camera identifier.");
+    if (!cam) return fail(c, SS_ERR_INVALID_ARG, "Calibration message missing structured parameter payload.");
+    c->cam = *cam;
+    c->cam.type[sizeof(c->cam.type) - 1] = 0;
+    c->cam_id = camera_id;
+    c->calibrated = true;
+    return SS_OK;
+}
+
+int ss_extract(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height, int channels, int row_stride,
+               double timestamp, ss_frame_result *out)
+{
+    if (!c || !out) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (camera_id == 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing camera identifier.");
+    if (!pix || width <= 0 || height <= 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing binary image data.");
+    if (channels != 1 && channels != 3 && channels != 4) return fail(c, SS_ERR_BAD_FRAME, "unsupported channel count");
+    if (channels != 1 && !c->calibrated)
+        return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    if (row_stride < width * channels) return fail(c, SS_ERR_BAD_FRAME, "row_stride smaller than a row");
+    int rc = ensure_geometry(c, width, height);
+    if (rc != SS_OK) return rc;
+    const size_t bytes = (size_t)row_stride * height;
+    rc = grow(c, c->d_in, c->d_in_bytes, bytes);
+    if (rc != SS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, pix, bytes, hipMemcpyHostToDevice, c->stream));
+    /* the caller keeps ownership of pix: it is consumed before we return */
+    rc = run_extract(c, c->d_in, 1, channels, row_stride, (int64_t)bytes);
+    if (rc != SS_OK) return rc;
+    int32_t nk = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nk, c->n_kp, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out->level_counts, c->level_counts, SS_MAX_LEVELS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    rc = check_frame_errors(c); /* synchronises */
+    if (rc != SS_OK) return rc;
+    c->h_kps.resize((size_t)std::max(nk, 1));
+    c->h_desc.resize((size_t)std::max(nk, 1) * SS_DESC_BYTES);
+    if (nk > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_kps.data(), c->kps, (size_t)nk * sizeof(ss_keypoint), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_desc.data(), c->desc, (size_t)nk * SS_DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    out->n_keypoints = nk;
+    out->camera_id = camera_id;
+    out->timestamp = timestamp;
+    out->keypoints = c->h_kps.data();
+    out->descriptors = c->h_desc.data();
+    return SS_OK;
+}
+
+int ss_extract_batch_device(ss_ctx *c, const void *d_pix, int n_frames, int width, int height, int channels,
+                            int64_t row_stride, int64_t frame_stride)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!d_pix || n_frames < 1 || width <= 0 || height <= 0) return fail(c, SS_ERR_BAD_FRAME, "empty batch");
+    if (n_frames > c->params.max_batch) return fail(c, SS_ERR_INVALID_ARG, "n_frames exceeds max_batch of this context");
+    if (channels != 1 && channels != 3 && channels != 4) return fail(c, SS_ERR_BAD_FRAME, "unsupported channel count");
+    if (channels != 1 && !c->calibrated)
+        return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    if (row_stride < (int64_t)width * channels || frame_stride < row_stride * height)
+        return fail(c, SS_ERR_BAD_FRAME, "strides smaller than the frame");
+    int rc = ensure_geometry(c, width, height);
+    if (rc != SS_OK) return rc;
+    return run_extract(c, d_pix, n_frames, channels, row_stride, frame_stride);
+}
+
+int ss_get_batch_view(ss_ctx *c, ss_batch_view *out)
+{
+    if (!c || !out) return SS_ERR_INVALID_ARG;
+    if (!c->have_geom || c->last_n_frames <= 0) return fail(c, SS_ERR_STATE, "no batch has been extracted");
+    out->n_frames = c->last_n_frames;
+    out->kp_capacity = c->hg.kcap;
+    out->keypoints = c->kps;
+    out->descriptors = c->desc;
+    out->n_keypoints = c->n_kp;
+    out->level_counts = c->level_counts;
+    return SS_OK;
+}
+
+int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_train, int n_train, int th,
+                    int ratio_num, int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_query < 0 || n_train < 0 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
+    if (n_query == 0) return SS_OK;
+    if (!d_query || (!d_train && n_train > 0) || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    int chunk_len = 4;
+    const int n_chunks = ssk_match_chunks(n_query, std::max(n_train, 1), 1, &chunk_len);
+    if (n_chunks > 1) {
+        int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_chunks * n_query * SSK_MATCH_PARTIAL_BYTES);
+        if (rc != SS_OK) return rc;
+    }
+    {
+        stage_timer t(c, "match", (int64_t)n_query * 32 + (int64_t)n_train * 32 + (int64_t)n_query * 8);
+        ssk_match(c->stream, d_query, d_train ? d_train : d_query, nullptr, nullptr, n_query, n_train, 0, 0, 0, chunk_len,
+                  n_chunks, exclude_self ? 1 : 0, th, ratio_num, ratio_den, n_query, c->match_partial, (int32_t *)d_idx,
+                  (uint16_t *)d_d1, (uint16_t *)d_d2, 1);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_match(ss_ctx *c, const uint8_t *query, int n_query, const uint8_t *train, int n_train, int th, int ratio_num,
+             int ratio_den, int exclude_self, int32_t *idx, uint16_t *d1, uint16_t *d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_query < 0 || n_train < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
+    if (n_query == 0) return SS_OK;
+    if (!query || (!train && n_train > 0) || !idx || !d1 || !d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    int rc = grow(c, c->d_mq, c->d_mq_bytes, (size_t)n_query * 32);
+    if (rc == SS_OK) rc = grow(c, c->d_mt, c->d_mt_bytes, (size_t)std::max(n_train, 1) * 32);
+    if (rc == SS_OK) rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n_query * 8);
+    if (rc != SS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_mq, query, (size_t)n_query * 32, hipMemcpyHostToDevice, c->stream));
+    if (n_train > 0) HIP_TRY(c, hipMemcpyAsync(c->d_mt, train, (size_t)n_train * 32, hipMemcpyHostToDevice, c->stream));
+    int32_t *di = (int32_t *)c->d_mout;
+    uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n_query * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n_query * 6);
+    rc = ss_match_device(c, c->d_mq, n_query, c->d_mt, n_train, th, ratio_num, ratio_den, exclude_self, di, dd1, dd2);
+    if (rc != SS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(idx, di, (size_t)n_query * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d1, dd1, (size_t)n_query * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d2, dd2, (size_t)n_query * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_den, void *d_idx, void *d_d1, void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->have_geom || c->last_n_frames <= 0) return fail(c, SS_ERR_STATE, "no batch has been extracted");
+    if ((mode != 0 && mode != 1) || !d_idx || !d_d1 || !d_d2 || ratio_den <= 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
+    const int n = c->last_n_frames, kcap = c->hg.kcap;
+    int chunk_len = 4;
+    const int n_chunks = ssk_match_chunks(kcap, kcap, n, &chunk_len);
+    if (n_chunks > 1) {
+        int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n * n_chunks * kcap * SSK_MATCH_PARTIAL_BYTES);
+        if (rc != SS_OK) return rc;
+    }
+    {
+        const int64_t nf = c->hg.n_features;
+        stage_timer t(c, "match", (int64_t)n * (nf * 32 * 2 + nf * 8));
+        ssk_match(c->stream, c->desc, c->desc, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 8, (int64_t)kcap * 8,
+                  mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
+                  c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_synchronize(ss_ctx *c)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->have_geom && c->last_n_frames > 0) return check_frame_errors(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+int ss_get_stream(ss_ctx *c, void **hip_stream)
+{
+    if (!c || !hip_stream) return SS_ERR_INVALID_ARG;
+    *hip_stream = (void *)c->stream;
+    return SS_OK;
+}
+
+int ss_profile_enable(ss_ctx *c, int on)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    c->profile = on != 0;
+    return SS_OK;
+}
+
+int ss_profile_reset(ss_ctx *c)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_events(c);
+    for (auto &s : c->stages) s.ms.clear();
+    return SS_OK;
+}
+
+int ss_stats(ss_ctx *c, ss_stage_stats *out, int max_stages)
+{
+    if (!c || (!out && max_stages > 0)) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    int n = 0;
+    for (auto &s : c->stages) {
+        if (n < max_stages) {
+            ss_stage_stats &o = out[n];
+            memset(&o, 0, sizeof(o));
+            snprintf(o.name, sizeof(o.name), "%s", s.name.c_str());
+            o.launches = (int64_t)s.ms.size();
+            o.algorithmic_bytes = s.bytes;
+            if (!s.ms.empty()) {
+                std::vector<float> v = s.ms;
+                std::sort(v.begin(), v.end());
+                double tot = 0;
+                for (float x : v) tot += x;
+                o.total_ms = tot;
+                o.mean_ms = tot / v.size();
+                o.median_ms = v[v.size() / 2]; /* the shim's median rule, :661 */
+            }
+        }
+        n++;
+    }
+    return n;
+}
+
+int ss_debug_fetch(ss_ctx *c, int what, int frame, int level, void *dst, int64_t dst_bytes)
+{
+    if (!c || !dst) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->have_geom || frame < 0 || frame >= c->last_n_frames || level < 0 || level >= c->hg.n_levels)
+        return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: no such frame / level");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const ss_geom &g = c->hg;
+    const ss_level &L = g.lv[level];
+    if (what >= 0 && what <= 2) {
+        const uint8_t *base = what == 0 ? c->pyr : what == 1 ? c->blur : c->score;
+        const int64_t need = (int64_t)L.w * L.h;
+        if (dst_bytes < need) return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: dst too small");
+        HIP_TRY(c, hipMemcpy2D(dst, (size_t)L.w, base + (size_t)frame * g.block_bytes + L.off, (size_t)L.pitch,
+                               (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+        return (int)need;
+    }
+    if (what == 3 || what == 4) {
+        ss_level_state st;
+        HIP_TRY(c, hipMemcpy(&st, c->state + (size_t)frame * SS_MAX_LEVELS + level, sizeof(st), hipMemcpyDeviceToHost));
+        const int n = what == 3 ? st.n_cand : st.n_sel;
+        if (dst_bytes < (int64_t)n * 12) return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: dst too small");
+        std::vector<uint32_t> packed((size_t)std::max(n, 1));
+        const uint32_t *src = what == 3 ? c->cand + (size_t)frame * g.cand_total + L.cand_base
+                                        : c->sel + (size_t)frame * g.sel_total + L.sel_base;
+        if (n > 0) HIP_TRY(c, hipMemcpy(packed.data(), src, (size_t)n * 4, hipMemcpyDeviceToHost));
+        int32_t *o = (int32_t *)dst;
+        for (int i = 0; i < n; i++) {
+            o[3 * i] = SS_PX(packed[i]);
+            o[3 * i + 1] = SS_PY(packed[i]);
+            o[3 * i + 2] = SS_PR(packed[i]);
+        }
+        return n * 12;
+    }
+    return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: unknown selector");
+}
+
+} /* extern "C" */

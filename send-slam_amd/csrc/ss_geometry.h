@@ -1,0 +1,19 @@
+/* ss_geometry.h -- host-side geometry / layout builder (see ss_geometry.cpp). */
+#ifndef SS_GEOMETRY_H
+#define SS_GEOMETRY_H
+
+#include <string>
+#include <vector>
+
+#include "../../include/sendslam_orb.h"
+#include "ss_layout.h"
+
+struct ss_host_tables {
+    std::vector<ss_rtab> rtab;   /* resize coefficient tables, all levels */
+    std::vector<uint32_t> tiles; /* level << 20 | tile_y << 8 | tile_x, all levels */
+};
+
+int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
+                      ss_host_tables *tabs, std::string *err);
+
+#endif

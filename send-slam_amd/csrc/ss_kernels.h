@@ -1,0 +1,39 @@
+/* ss_kernels.h -- host-callable launch wrappers of ss_kernels.hip (all asynchronous on `s`). */
+#ifndef SS_KERNELS_H
+#define SS_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sendslam_orb.h"
+#include "ss_layout.h"
+
+void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride, int64_t frame_stride,
+                int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
+void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
+                int level, int n_frames);
+void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
+                    const uint32_t *tiles, int n_frames);
+void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+              const uint32_t *tiles, int n_frames);
+void ssk_cells(hipStream_t s, bool emit, const uint8_t *score, const ss_geom *dg, const ss_geom &hg,
+               int32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames);
+void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
+                  uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state,
+                  int n_frames);
+void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_level_state *state, uint32_t *kp_ref,
+               int32_t *n_kp, int32_t *level_counts, int32_t *frame_error, int n_frames);
+void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
+                         const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
+                         uint8_t *desc, int n_frames);
+
+/* train split so that a launch has >> 256 workgroups and local indices fit 16 bits */
+int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len);
+/* strides in 32-bit words; exclude_self_mode: 0 never, 1 always, 2 when train frame == query frame */
+void ssk_match(hipStream_t s, const void *query, const void *train, const int32_t *nq_arr, const int32_t *nt_arr,
+               int nq_fixed, int nt_fixed, int64_t q_frame_stride_words, int64_t t_frame_stride_words,
+               int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
+               int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames);
+#define SSK_MATCH_PARTIAL_BYTES 8
+
+#endif

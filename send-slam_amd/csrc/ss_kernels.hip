@@ -1,0 +1,1162 @@
+/*
+ * ss_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ORB hot path.
+ *
+ * Stage map; the reference's implementation of every stage is the
+ * unvendored ORB-SLAM3 library entered at
+ * /root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc:594:
+ *   K0  k_ingest        cvtColor RGB/BGR -> gray (or pitched copy) into pyramid level 0
+ *   K1  k_resize        ORBextractor::ComputePyramid: cv::resize INTER_LINEAR, level by level
+ *   K2  k_fast_score    cv::FAST-9-16 corner response R-1 for every pixel (threshold-free)
+ *   K3  k_cells<EMIT>   35-px cell grid: NMS inside the cell, iniTh -> minTh fallback,
+ *                       ordered compaction into the candidate list
+ *   K4  k_quadtree      ORBextractor::DistributeOctTree, one wave per (frame, level)
+ *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
+ *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
+ *   K6a k_blur          GaussianBlur 7x7 sigma 2, 8-bit fixed-point path
+ *   K7  k_match / k_match_merge   Hamming best / second best + ratio test
+ *
+ * Integer / byte work throughout: no MFMA (nothing here is a dense contraction).  Every
+ * kernel takes the batch slot in blockIdx.y or .z so one launch covers a batch of frames.
+ * Float steps are single IEEE operations (-ffp-contract=off, ss_float_steps.h).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ss_constants.h"
+#include "ss_float_steps.h"
+#include "ss_kernels.h"
+#include "ss_layout.h"
+
+#define WAVE 64
+
+namespace {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    return ((uint64_t)1 << lane_id()) - 1;
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int min3(int a, int b, int c) { return imin(imin(a, b), c); }
+__device__ __forceinline__ int max3(int a, int b, int c) { return imax(imax(a, b), c); }
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K0: ingest.  channels == 1: pitched copy; 3/4: fixed-point gray, c0/c1/c2 = weights of   */
+/* byte 0/1/2 (host swaps RY/BY with the calibration's rgb flag).  4 pixels per thread.    */
+/* ------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t *__restrict__ src, int channels,
+                                                int64_t row_stride, int64_t frame_stride,
+                                                int c0, int c1, int c2, uint8_t *__restrict__ pyr,
+                                                const ss_geom *__restrict__ g)
+{
+    const int w = g->lv[0].w, h = g->lv[0].h, pitch = g->lv[0].pitch;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h || x4 >= w) return;
+    const uint8_t *s = src + (int64_t)blockIdx.z * frame_stride + (int64_t)y * row_stride;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = imin(x4 + i, w - 1);
+        uint32_t v;
+        if (channels == 1) {
+            v = s[x];
+        } else {
+            const uint8_t *p = s + (int64_t)x * channels;
+            v = (uint32_t)(p[0] * c0 + p[1] * c1 + p[2] * c2 + (1 << (SS_GRAY_SHIFT - 1))) >> SS_GRAY_SHIFT;
+        }
+        out |= (v & 0xFFu) << (8 * i);
+    }
+    *(uint32_t *)(pyr + (size_t)blockIdx.z * g->block_bytes + g->lv[0].off + (size_t)y * pitch + x4) = out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K1: one pyramid step.  Host tables hold OpenCV's fixed-point taps (ss_geometry.cpp).   */
+/* ------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
+                                                const ss_rtab *__restrict__ rtab, int level)
+{
+    const ss_level &D = g->lv[level];
+    const ss_level &S = g->lv[level - 1];
+    const int dx4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dy >= D.h || dx4 >= D.w) return;
+    uint8_t *base = pyr + (size_t)blockIdx.z * g->block_bytes;
+    const uint8_t *src = base + S.off;
+    const ss_rtab ty = rtab[D.ytab_off + dy];
+    const uint8_t *r0 = src + (size_t)ty.s0 * S.pitch, *r1 = src + (size_t)ty.s1 * S.pitch;
+    const int b0 = ty.a0, b1 = ty.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const ss_rtab tx = rtab[D.xtab_off + dx4 + i]; /* table padded past w */
+        const int h0 = r0[tx.s0] * tx.a0 + r0[tx.s1] * tx.a1;
+        const int h1 = r1[tx.s0] * tx.a0 + r1[tx.s1] * tx.a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out |= ((uint32_t)v & 0xFFu) << (8 * i);
+    }
+    *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K2: FAST-9-16 response.  R = max over the 16 arcs of 9 contiguous ring pixels of        */
+/* min(v - p) and of min(p - v); a pixel is a corner at threshold t iff R > t and its      */
+/* cv::cornerScore is R - 1 for every such t, so ONE map serves iniTh and minTh.  Stored:  */
+/* R - 1 if R > minTh else 0.  64x16 tile per 256-thread block, 4 pixels per thread; the   */
+/* tile plus its 3-px ring halo is staged in LDS as aligned dwords.                        */
+/* ------------------------------------------------------------------------------------ */
+#define FT_ROWS (SS_TILE_H + 6)
+#define FT_WORDS (SS_TILE_W / 4 + 2)
+
+__device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k compile-time */
+{
+    return (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr,
+                                                    uint8_t *__restrict__ score,
+                                                    const ss_geom *__restrict__ g,
+                                                    const uint32_t *__restrict__ tiles)
+{
+    __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
+    const uint32_t t = tiles[blockIdx.x];
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const ss_level &L = g->lv[level];
+    const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
+    const uint8_t *img = pyr + fb;
+    const int w = L.w, h = L.h, pitch = L.pitch;
+
+    for (int idx = threadIdx.x; idx < FT_ROWS * FT_WORDS; idx += 256) {
+        const int r = idx / FT_WORDS, c = idx - r * FT_WORDS;
+        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < pitch) v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
+        lds[r][c] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    uint32_t rw[7][3];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) rw[r][c] = lds[ty + r][tx + c];
+    }
+    constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    const int min_th = g->min_th;
+    const int y = y0 + ty;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = tile_byte(rw[3], 4 + i);
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - tile_byte(rw[3 + RDY[k]], 4 + i + RDX[k]);
+        int lo3[16], hi3[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            lo3[k] = min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+            hi3[k] = max3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        }
+        int dark = -256, bright = 256; /* max over arcs of min(d); min over arcs of max(d) */
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            dark = imax(dark, min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+            bright = imin(bright, max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        }
+        const int R = imax(dark, -bright);
+        const int x = x0 + 4 * tx + i;
+        const bool inside = x >= 3 && x < w - 3 && y >= 3 && y < h - 3;
+        const uint32_t s = (inside && R > min_th) ? (uint32_t)(R - 1) : 0u;
+        out |= s << (8 * i);
+    }
+    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K6a: 7x7 sigma-2 Gaussian, OpenCV 8U fixed-point path: horizontal taps in 8 fractional */
+/* bits to u16, vertical taps to 16 fractional bits, + 2^15 >> 16.  BORDER_REFLECT_101 is   */
+/* applied while staging the tile (no stored border).                                     */
+/* ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * n - 2 - p;
+    return p < 0 ? 0 : (p >= n ? n - 1 : p);
+}
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              const ss_geom *__restrict__ g,
+                                              const uint32_t *__restrict__ tiles)
+{
+    __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
+    __shared__ uint32_t hbuf[FT_ROWS][SS_TILE_W / 2]; /* u16 x 64 per row */
+    const uint32_t t = tiles[blockIdx.x];
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const ss_level &L = g->lv[level];
+    const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
+    const uint8_t *img = pyr + fb;
+    const int w = L.w, h = L.h, pitch = L.pitch;
+
+    for (int idx = threadIdx.x; idx < FT_ROWS * FT_WORDS; idx += 256) {
+        const int r = idx / FT_WORDS, c = idx - r * FT_WORDS;
+        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
+        uint32_t v;
+        if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
+            v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
+        } else {
+            const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
+            v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+        }
+        lds[r][c] = v;
+    }
+    __syncthreads();
+
+    for (int idx = threadIdx.x; idx < FT_ROWS * 16; idx += 256) {
+        const int r = idx >> 4, q = idx & 15;
+        const uint32_t rw[3] = {lds[r][q], lds[r][q + 1], lds[r][q + 2]};
+        uint32_t hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hv[i] = (uint32_t)(SS_GAUSS_K0 * (tile_byte(rw, 1 + i) + tile_byte(rw, 7 + i)) +
+                               SS_GAUSS_K1 * (tile_byte(rw, 2 + i) + tile_byte(rw, 6 + i)) +
+                               SS_GAUSS_K2 * (tile_byte(rw, 3 + i) + tile_byte(rw, 5 + i)) +
+                               SS_GAUSS_K3 * tile_byte(rw, 4 + i));
+        }
+        hbuf[r][2 * q] = hv[0] | (hv[1] << 16);
+        hbuf[r][2 * q + 1] = hv[2] | (hv[3] << 16);
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int y = y0 + ty;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    constexpr uint32_t KV[7] = {SS_GAUSS_K0, SS_GAUSS_K1, SS_GAUSS_K2, SS_GAUSS_K3, SS_GAUSS_K2, SS_GAUSS_K1, SS_GAUSS_K0};
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const uint32_t a = hbuf[ty + j][2 * tx], b = hbuf[ty + j][2 * tx + 1];
+        acc[0] += KV[j] * (a & 0xFFFFu);
+        acc[1] += KV[j] * (a >> 16);
+        acc[2] += KV[j] * (b & 0xFFFFu);
+        acc[3] += KV[j] * (b >> 16);
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) out |= (((acc[i] + 32768u) >> 16) & 0xFFu) << (8 * i);
+    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(blur + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K3: one wave per grid cell.  The cell's evaluated window of the score map (plus a zero  */
+/* 1-px frame: FAST_t's ring buffers hold 0 outside the evaluated window) is staged in LDS;*/
+/* NMS = strictly greater than all 8 neighbours at the cell's threshold; if no keypoint    */
+/* survives at iniTh the cell is redone at minTh.  COUNT pass: survivors per cell.  EMIT   */
+/* pass: ordered compaction (cells row-major, pixels row-major inside a cell = upstream's  */
+/* push_back order) via ballot + prefix.                                                   */
+/* ------------------------------------------------------------------------------------ */
+#define CELL_PITCH 72
+#define CELL_ROWS 72
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void k_cells(const uint8_t *__restrict__ score,
+                                              const ss_geom *__restrict__ g, int32_t *__restrict__ cell_cnt,
+                                              uint32_t *__restrict__ cand, ss_level_state *__restrict__ state)
+{
+    __shared__ uint8_t tile[CELL_ROWS][CELL_PITCH];
+    const int frame = blockIdx.y, cell = blockIdx.x;
+    int level = 0;
+    for (int l = 1; l < g->n_levels; l++)
+        if (cell >= g->lv[l].cell_base) level = l;
+    const ss_level &L = g->lv[level];
+    const int loc = cell - L.cell_base;
+    const int ci = loc / L.n_cols, cj = loc - ci * L.n_cols;
+    const int lane = lane_id();
+    int32_t *cnt = cell_cnt + (size_t)frame * g->n_cells;
+    const bool last_cell = loc == L.n_cols * L.n_rows - 1;
+
+    const int max_bx = L.w - SS_EDGE_THRESHOLD + 3, max_by = L.h - SS_EDGE_THRESHOLD + 3;
+    const int ini_y = SS_MIN_BORDER + ci * L.h_cell, ini_x = SS_MIN_BORDER + cj * L.w_cell;
+    const int max_y = imin(ini_y + L.h_cell + 6, max_by), max_x = imin(ini_x + L.w_cell + 6, max_bx);
+    const bool skipped = ini_y >= max_by - 3 || ini_x >= max_bx - 6;
+    const int ex0 = ini_x + 3, ey0 = ini_y + 3;
+    const int ew = skipped ? 0 : imax(max_x - 3 - ex0, 0), eh = skipped ? 0 : imax(max_y - 3 - ey0, 0);
+
+    int count = 0;
+    bool use_ini = false;
+    if (ew > 0 && eh > 0) {
+        const uint8_t *sm = score + (size_t)frame * g->block_bytes + L.off;
+        for (int r = 0; r < eh + 2; r++) {
+            for (int c = lane; c < ew + 2; c += WAVE) {
+                uint8_t v = 0;
+                if (r >= 1 && r <= eh && c >= 1 && c <= ew)
+                    v = sm[(size_t)(ey0 - 1 + r) * L.pitch + (ex0 - 1 + c)];
+                tile[r][c] = v;
+            }
+        }
+        __syncthreads();
+        const int ini_th = g->ini_th;
+        int n_ini = 0, n_min = 0;
+        if (!EMIT) {
+            for (int r = 1; r <= eh; r++) {
+                for (int cb = 1; cb <= ew; cb += WAVE) {
+                    const int c = cb + lane;
+                    bool k_ini = false, k_min = false;
+                    if (c <= ew) {
+                        const int s = tile[r][c];
+                        if (s > 0) {
+                            int m = 0, m_ini = 0;
+#pragma unroll
+                            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                                for (int dx = -1; dx <= 1; dx++) {
+                                    if (dx == 0 && dy == 0) continue;
+                                    const int n = tile[r + dy][c + dx];
+                                    m = imax(m, n);
+                                    m_ini = imax(m_ini, n >= ini_th ? n : 0);
+                                }
+                            k_min = s > m;
+                            k_ini = s >= ini_th && s > m_ini;
+                        }
+                    }
+                    n_ini += __popcll(__ballot(k_ini));
+                    n_min += __popcll(__ballot(k_min));
+                }
+            }
+            use_ini = n_ini > 0;
+            count = use_ini ? n_ini : n_min;
+        } else {
+            const int stored = cnt[cell];
+            use_ini = (stored >> 30) & 1;
+            count = stored & 0x3FFFFFFF;
+        }
+    }
+    if (!EMIT) {
+        if (lane == 0) cnt[cell] = count | (use_ini ? (1 << 30) : 0);
+        return;
+    }
+
+    /* EMIT: offset = survivors of all earlier cells of this level */
+    int before = 0;
+    for (int c = L.cell_base + lane; c < cell; c += WAVE) before += cnt[c] & 0x3FFFFFFF;
+    before = wave_sum(before);
+    ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
+    if (before + count > L.cand_cap) {
+        if (lane == 0) atomicExch(&st->error, -5);
+        return;
+    }
+    if (last_cell && lane == 0) st->n_cand = before + count;
+    if (count == 0) return;
+    uint32_t *out = cand + (size_t)frame * g->cand_total + L.cand_base;
+    const int ini_th = g->ini_th;
+    int pos = before;
+    for (int r = 1; r <= eh; r++) {
+        for (int cb = 1; cb <= ew; cb += WAVE) {
+            const int c = cb + lane;
+            bool keep = false;
+            int s = 0;
+            if (c <= ew) {
+                s = tile[r][c];
+                if (s > 0 && (!use_ini || s >= ini_th)) {
+                    int m = 0;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int n = tile[r + dy][c + dx];
+                            m = imax(m, (!use_ini || n >= ini_th) ? n : 0);
+                        }
+                    keep = s > m;
+                }
+            }
+            const uint64_t mask = __ballot(keep);
+            if (keep) {
+                const int x = ex0 - 1 + c, y = ey0 - 1 + r; /* level coordinates */
+                out[pos + __popcll(mask & lanemask_lt())] = SS_PACK(x - SS_MIN_BORDER, y - SS_MIN_BORDER, s);
+            }
+            pos += __popcll(mask);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K4: DistributeOctTree, array form (DESIGN.md "quadtree"): std::list with push_front /   */
+/* erase == append-only node table whose list order is DESCENDING creation index; every    */
+/* node owns a contiguous, order-preserving segment of a record array (ping-pong buffers), */
+/* so DivideNode is a stable 4-way partition done with ballots.  One wave per tree.        */
+/* std::sort(compareNodes) is libstdc++ introsort restated on lane 0 (equal keys must come */
+/* out in libstdc++'s order; tests pin the restatement against the real std::sort).        */
+/* ------------------------------------------------------------------------------------ */
+#define QT_MAX_ITEMS 4096
+
+/* sort item: size[63:32] | UL.x[31:20] | node index[19:0]; compareNodes looks at (size, UL.x) only */
+__device__ __forceinline__ bool item_less(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
+
+__device__ void sort_push_heap(uint64_t *first, int hole, int top, uint64_t value)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && item_less(first[parent], value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+__device__ void sort_adjust_heap(uint64_t *first, int hole, int len, uint64_t value)
+{
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (item_less(first[second], first[second - 1])) second--;
+        first[hole] = first[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        first[hole] = first[second - 1];
+        hole = second - 1;
+    }
+    sort_push_heap(first, hole, top, value);
+}
+__device__ void sort_heap_range(uint64_t *first, int n)
+{
+    if (n >= 2) {
+        int parent = (n - 2) / 2;
+        for (;;) {
+            sort_adjust_heap(first, parent, n, first[parent]);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int last = n;
+    while (last > 1) {
+        --last;
+        const uint64_t v = first[last];
+        first[last] = first[0];
+        sort_adjust_heap(first, 0, last, v);
+    }
+}
+__device__ __forceinline__ void sort_unguarded_linear_insert(uint64_t *a, int last)
+{
+    const uint64_t val = a[last];
+    int next = last - 1;
+    while (item_less(val, a[next])) {
+        a[last] = a[next];
+        last = next;
+        --next;
+    }
+    a[last] = val;
+}
+__device__ void sort_insertion(uint64_t *a, int first, int last)
+{
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (item_less(a[i], a[first])) {
+            const uint64_t val = a[i];
+            for (int k = i; k > first; --k) a[k] = a[k - 1];
+            a[first] = val;
+        } else
+            sort_unguarded_linear_insert(a, i);
+    }
+}
+/* std::sort(a, a + n, compareNodes), single lane */
+__device__ void std_sort_items(uint64_t *a, int n)
+{
+    if (n <= 0) return;
+    int lg = 0;
+    for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
+    /* __introsort_loop with an explicit stack for the recursive (right) halves */
+    int stack_first[64], stack_last[64], stack_depth[64];
+    int sp = 0;
+    stack_first[0] = 0;
+    stack_last[0] = n;
+    stack_depth[0] = lg * 2;
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) {
+                sort_heap_range(a + first, last - first);
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            int pick; /* __move_median_to_first */
+            if (item_less(a[ia], a[ib])) {
+                if (item_less(a[ib], a[ic])) pick = ib;
+                else if (item_less(a[ia], a[ic])) pick = ic;
+                else pick = ia;
+            } else if (item_less(a[ia], a[ic])) pick = ia;
+            else if (item_less(a[ib], a[ic])) pick = ic;
+            else pick = ib;
+            {
+                const uint64_t tmp = a[first];
+                a[first] = a[pick];
+                a[pick] = tmp;
+            }
+            int lo = first + 1, hi = last; /* __unguarded_partition */
+            for (;;) {
+                while (item_less(a[lo], a[first])) ++lo;
+                --hi;
+                while (item_less(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                const uint64_t tmp = a[lo];
+                a[lo] = a[hi];
+                a[hi] = tmp;
+                ++lo;
+            }
+            if (sp < 64) {
+                stack_first[sp] = lo;
+                stack_last[sp] = last;
+                stack_depth[sp] = depth;
+                ++sp;
+            }
+            last = lo;
+        }
+    }
+    if (n > 16) {
+        sort_insertion(a, 0, 16);
+        for (int i = 16; i != n; ++i) sort_unguarded_linear_insert(a, i);
+    } else
+        sort_insertion(a, 0, n);
+}
+
+struct qt_ctx {
+    uint32_t *buf[2];
+    ss_qnode *nodes;
+    int node_cap;
+    int n_nodes;
+    int size; /* lNodes.size() */
+    int error;
+};
+
+/* ExtractorNode::DivideNode on node idx.  Returns the number of children made; their node
+ * indices are n_nodes_before .. n_nodes_before + made - 1 in n1..n4 order. */
+__device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by creation order */)
+{
+    const ss_qnode nd = q.nodes[idx];
+    const int x0 = rfl(nd.x0), x1 = rfl(nd.x1), y0 = rfl(nd.y0), y1 = rfl(nd.y1);
+    const int beg = rfl(nd.beg), cnt = rfl(nd.cnt), b = (rfl(nd.flags) >> 2) & 1;
+    const int xm = x0 + ((x1 - x0 + 1) >> 1); /* ceil((float)(UR.x-UL.x)/2) */
+    const int ym = y0 + ((y1 - y0 + 1) >> 1);
+    const uint32_t *src = q.buf[b] + beg;
+    uint32_t *dst = q.buf[b ^ 1] + beg;
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+
+    int c[4] = {0, 0, 0, 0};
+    uint32_t rec0 = 0;
+    int q0 = 4;
+    for (int base = 0; base < cnt; base += WAVE) {
+        const int i = base + lane;
+        uint32_t rec = 0;
+        int quad = 4;
+        if (i < cnt) {
+            rec = src[i];
+            quad = (SS_PX(rec) >= xm ? 1 : 0) | (SS_PY(rec) >= ym ? 2 : 0);
+        }
+        if (base == 0) { rec0 = rec; q0 = quad; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(quad == k));
+    }
+    int run[4];
+    run[0] = 0;
+    run[1] = c[0];
+    run[2] = c[0] + c[1];
+    run[3] = c[0] + c[1] + c[2];
+    const int o[4] = {run[0], run[1], run[2], run[3]};
+    for (int base = 0; base < cnt; base += WAVE) {
+        const int i = base + lane;
+        uint32_t rec = rec0;
+        int quad = q0;
+        if (base != 0) {
+            rec = 0;
+            quad = 4;
+            if (i < cnt) {
+                rec = src[i];
+                quad = (SS_PX(rec) >= xm ? 1 : 0) | (SS_PY(rec) >= ym ? 2 : 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t m = __ballot(quad == k);
+            if (quad == k) dst[run[k] + __popcll(m & lt)] = rec;
+            run[k] += __popcll(m);
+        }
+    }
+    __syncthreads();
+
+    if (q.n_nodes + 4 > q.node_cap) {
+        q.error = -5;
+        return 0;
+    }
+    const int rx0[4] = {x0, xm, x0, xm}, rx1[4] = {xm, x1, xm, x1};
+    const int ry0[4] = {y0, y0, ym, ym}, ry1[4] = {ym, ym, y1, y1};
+    int made = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (c[k] > 0) {
+            ss_qnode ch;
+            ch.x0 = (uint16_t)rx0[k];
+            ch.x1 = (uint16_t)rx1[k];
+            ch.y0 = (uint16_t)ry0[k];
+            ch.y1 = (uint16_t)ry1[k];
+            ch.beg = beg + o[k];
+            ch.cnt = c[k];
+            ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((b ^ 1) << 2);
+            if (lane == 0) q.nodes[q.n_nodes] = ch;
+            child_cnt[made] = c[k];
+            q.n_nodes++;
+            q.size++;
+            made++;
+        }
+    }
+    if (lane == 0) q.nodes[idx].flags = nd.flags & ~1; /* lNodes.erase */
+    q.size--;
+    __syncthreads();
+    return made;
+}
+
+__global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
+                                                 uint32_t *__restrict__ qbuf0, uint32_t *__restrict__ qbuf1,
+                                                 ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
+                                                 uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
+{
+    __shared__ uint64_t items[QT_MAX_ITEMS];
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const ss_level &L = g->lv[level];
+    ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const int n_cand = rfl(st->n_cand);
+    if (rfl(st->error) != 0 || n_cand == 0) {
+        if (lane == 0) st->n_sel = 0;
+        return;
+    }
+    const int N = L.quota;
+    const uint32_t *in = cand + (size_t)frame * g->cand_total + L.cand_base;
+    qt_ctx q;
+    q.buf[0] = qbuf0 + (size_t)frame * g->cand_total + L.cand_base;
+    q.buf[1] = qbuf1 + (size_t)frame * g->cand_total + L.cand_base;
+    q.nodes = nodes_all + (size_t)frame * g->node_total + L.node_base;
+    q.node_cap = L.node_cap;
+    q.n_nodes = 0;
+    q.size = 0;
+    q.error = 0;
+    /* two expandable-node lists of item_cap ints each, swapped per pass */
+    int32_t *list_a = lists_all + ((size_t)frame * g->item_total + L.item_base) * 2;
+    int32_t *list_b = list_a + L.item_cap;
+    const int list_cap = L.item_cap;
+
+    /* roots: vpIniNodes[kp.pt.x / hX]; list order r0, r1, ... == descending creation index,
+     * so root i gets node index n_ini-1-i.  Stable partition of the candidates by root. */
+    const int n_ini = L.n_ini;
+    const float hx = L.hx;
+    const int height = (L.h - SS_EDGE_THRESHOLD + 3) - SS_MIN_BORDER;
+    int root_beg = 0;
+    for (int r = 0; r < n_ini; r++) {
+        int cnt_r = 0;
+        for (int base = 0; base < n_cand; base += WAVE) {
+            const int i = base + lane;
+            bool mine = false;
+            uint32_t rec = 0;
+            if (i < n_cand) {
+                rec = in[i];
+                mine = (int)((float)SS_PX(rec) / hx) == r;
+            }
+            const uint64_t m = __ballot(mine);
+            if (mine) q.buf[0][root_beg + cnt_r + __popcll(m & lt)] = rec;
+            cnt_r += __popcll(m);
+        }
+        ss_qnode nd;
+        nd.x0 = (uint16_t)(int)(hx * (float)r);
+        nd.x1 = (uint16_t)(int)(hx * (float)(r + 1));
+        nd.y0 = 0;
+        nd.y1 = (uint16_t)height;
+        nd.beg = root_beg;
+        nd.cnt = cnt_r;
+        nd.flags = (cnt_r > 0 ? 1 : 0) | (cnt_r == 1 ? 2 : 0); /* empty roots are erased */
+        if (lane == 0) q.nodes[n_ini - 1 - r] = nd;
+        if (cnt_r > 0) q.size++;
+        root_beg += cnt_r;
+    }
+    q.n_nodes = n_ini;
+    __syncthreads();
+    if (root_beg != n_cand) q.error = -5; /* a candidate outside every root: cannot happen */
+
+    /* expandable roots in creation order (= root n_ini-1 first) */
+    int32_t *cur = list_a, *nxt = list_b;
+    int n_cur = 0;
+    for (int idx = 0; idx < n_ini; idx++) {
+        const int fl = rfl(q.nodes[idx].flags);
+        if ((fl & 1) && !(fl & 2)) {
+            if (lane == 0) cur[n_cur] = idx;
+            n_cur++;
+        }
+    }
+    __syncthreads();
+
+    bool finish = false;
+    while (!finish && q.error == 0) {
+        const int prev_size = q.size;
+        int n_to_expand = 0, n_nxt = 0;
+        /* one full pass: lit walks the list (descending creation index); every node that
+         * existed at the start and is not final is divided */
+        for (int k = n_cur - 1; k >= 0 && q.error == 0; k--) {
+            const int idx = rfl(cur[k]);
+            int cc[4];
+            const int first_child = q.n_nodes;
+            const int made = qt_split(q, idx, cc);
+            for (int m = 0; m < made; m++)
+                if (cc[m] > 1) {
+                    n_to_expand++;
+                    if (n_nxt < list_cap) {
+                        if (lane == 0) nxt[n_nxt] = first_child + m;
+                    } else
+                        q.error = -5;
+                    n_nxt++;
+                }
+        }
+        __syncthreads();
+        { int32_t *t = cur; cur = nxt; nxt = t; }
+        n_cur = n_nxt;
+        if (q.error) break;
+        if (q.size >= N || q.size == prev_size) {
+            finish = true;
+        } else if (q.size + n_to_expand * 3 > N) {
+            while (!finish && q.error == 0) {
+                const int prev2 = q.size;
+                const int n_prev = n_cur;
+                if (n_prev > QT_MAX_ITEMS) { q.error = -5; break; }
+                /* vPrevSizeAndPointerToNode, in creation order; key = size, then UL.x */
+                for (int j = lane; j < n_prev; j += WAVE) {
+                    const int idx = cur[j];
+                    const ss_qnode nd = q.nodes[idx];
+                    items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
+                }
+                __syncthreads();
+                if (lane == 0) std_sort_items(items, n_prev);
+                __syncthreads();
+                n_nxt = 0;
+                for (int j = n_prev - 1; j >= 0 && q.error == 0; j--) {
+                    const int idx = rfl((int)((uint32_t)items[j] & 0xFFFFFu));
+                    int cc[4];
+                    const int first_child = q.n_nodes;
+                    const int made = qt_split(q, idx, cc);
+                    for (int m = 0; m < made; m++)
+                        if (cc[m] > 1) {
+                            if (n_nxt < list_cap) {
+                                if (lane == 0) nxt[n_nxt] = first_child + m;
+                            } else
+                                q.error = -5;
+                            n_nxt++;
+                        }
+                    if (q.size >= N) break;
+                }
+                __syncthreads();
+                { int32_t *t = cur; cur = nxt; nxt = t; }
+                n_cur = n_nxt;
+                if (q.size >= N || q.size == prev2) finish = true;
+            }
+        }
+    }
+
+    /* retain the best point of each node, list order (descending creation index) */
+    uint32_t *out = sel + (size_t)frame * g->sel_total + L.sel_base;
+    int n_out = 0;
+    if (q.error == 0) {
+        for (int hi = q.n_nodes - 1; hi >= 0; hi -= WAVE) {
+            const int idx = hi - lane;
+            ss_qnode nd;
+            nd.flags = 0;
+            if (idx >= 0) nd = q.nodes[idx];
+            const bool alive = idx >= 0 && (nd.flags & 1);
+            const uint64_t m = __ballot(alive);
+            const int pos = n_out + __popcll(m & lt);
+            if (alive && pos < L.sel_cap) {
+                const uint32_t *seg = q.buf[(nd.flags >> 2) & 1] + nd.beg;
+                uint32_t best = seg[0];
+                for (int k = 1; k < nd.cnt; k++) {
+                    const uint32_t r = seg[k];
+                    if (SS_PR(r) > SS_PR(best)) best = r;
+                }
+                out[pos] = SS_PACK(SS_PX(best) + SS_MIN_BORDER, SS_PY(best) + SS_MIN_BORDER, SS_PR(best));
+            }
+            n_out += __popcll(m);
+        }
+        if (n_out > L.sel_cap) q.error = -5;
+    }
+    if (lane == 0) {
+        st->n_sel = q.error ? 0 : n_out;
+        if (q.error) atomicExch(&st->error, q.error);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ORBextractor::operator() output order: keypoints whose scaled x lies in the lapping     */
+/* area fill the arrays from the back (stereoIndex--), the others from the front           */
+/* (monoIndex++), levels in order.  One wave per frame computes each keypoint's slot.      */
+/* kp_ref[slot] = level << 16 | index in the level's selected list.                        */
+/* ------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, const uint32_t *__restrict__ sel,
+                                              const ss_level_state *__restrict__ state,
+                                              uint32_t *__restrict__ kp_ref, int32_t *__restrict__ n_kp,
+                                              int32_t *__restrict__ level_counts, int32_t *__restrict__ frame_error)
+{
+    const int frame = blockIdx.x, lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_;
+    int total = 0, err = 0;
+    for (int l = 0; l < g->n_levels; l++) {
+        total += st[l].n_sel;
+        if (st[l].error) err = st[l].error;
+    }
+    if (total > g->kcap) err = -5;
+    if (lane < SS_MAX_LEVELS_) level_counts[(size_t)frame * SS_MAX_LEVELS_ + lane] = lane < g->n_levels ? st[lane].n_sel : 0;
+    if (lane == 0) {
+        n_kp[frame] = err ? 0 : total;
+        frame_error[frame] = err;
+    }
+    if (err) return;
+    const float lap0 = (float)g->lap_x0, lap1 = (float)g->lap_x1;
+    uint32_t *ref = kp_ref + (size_t)frame * g->kcap;
+    int mono = 0, stereo = total - 1;
+    for (int l = 0; l < g->n_levels; l++) {
+        const ss_level &L = g->lv[l];
+        const uint32_t *s = sel + (size_t)frame * g->sel_total + L.sel_base;
+        const int n = st[l].n_sel;
+        for (int base = 0; base < n; base += WAVE) {
+            const int i = base + lane;
+            bool is_st = false, valid = i < n;
+            if (valid) {
+                float x = (float)SS_PX(s[i]);
+                if (l != 0) x = __fmul_rn(x, L.scale);
+                is_st = x >= lap0 && x <= lap1;
+            }
+            const uint64_t ms = __ballot(valid && is_st), mm = __ballot(valid && !is_st);
+            if (valid) {
+                const int slot = is_st ? stereo - __popcll(ms & lt) : mono + __popcll(mm & lt);
+                ref[slot] = ((uint32_t)l << 16) | (uint32_t)i;
+            }
+            stereo -= __popcll(ms);
+            mono += __popcll(mm);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K5 + K6b: one wave per keypoint.  IC_Angle: lanes = 31 rows x 2 halves of the radius-15 */
+/* disc, integer moments reduced across the wave, fastAtan2 restated.  rBRIEF: lane L does */
+/* pairs L, L+64, L+128, L+192; __ballot(t0 < t1) IS descriptor bytes 8k .. 8k+7 (bit i of  */
+/* byte j = test 8j+i).                                                                    */
+/* ------------------------------------------------------------------------------------ */
+__constant__ int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
+
+__global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
+                                                         const uint8_t *__restrict__ blur,
+                                                         const uint32_t *__restrict__ sel,
+                                                         const uint32_t *__restrict__ kp_ref,
+                                                         const int32_t *__restrict__ n_kp,
+                                                         ss_keypoint *__restrict__ kps, uint8_t *__restrict__ desc)
+{
+    const int frame = blockIdx.y;
+    const int slot = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (slot >= n_kp[frame]) return;
+    const int lane = lane_id();
+    const uint32_t ref = kp_ref[(size_t)frame * g->kcap + slot];
+    const int level = (int)(ref >> 16), i = (int)(ref & 0xFFFF);
+    const ss_level &L = g->lv[level];
+    const uint32_t rec = sel[(size_t)frame * g->sel_total + L.sel_base + i];
+    const int kx = SS_PX(rec), ky = SS_PY(rec), resp = SS_PR(rec);
+    const size_t fb = (size_t)frame * g->block_bytes + L.off;
+    const int pitch = L.pitch;
+
+    /* IC_Angle */
+    int m10 = 0, m01 = 0;
+    {
+        const int row = lane & 31, half = lane >> 5;
+        if (row < 31) {
+            const int v = row - SS_HALF_PATCH;
+            const int d = g->umax[v < 0 ? -v : v];
+            const uint8_t *p = pyr + fb + (size_t)(ky + v) * pitch + kx;
+            const int u0 = half ? 0 : -d, u1 = half ? d : -1;
+            int rs = 0;
+            for (int u = u0; u <= u1; u++) {
+                const int val = p[u];
+                m10 += u * val;
+                rs += val;
+            }
+            m01 = v * rs;
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = ss_fast_atan2((float)m01, (float)m10);
+    float b, a;
+    ss_sincosf_deg(angle, &b, &a);
+
+    /* steered rBRIEF */
+    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx;
+    uint64_t words[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int8_t *pt = c_pattern + 4 * (lane + 64 * k);
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        words[k] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        uint64_t *d = (uint64_t *)(desc + ((size_t)frame * g->kcap + slot) * SS_DESC_BYTES);
+        d[0] = words[0];
+        d[1] = words[1];
+        d[2] = words[2];
+        d[3] = words[3];
+        ss_keypoint kp;
+        kp.x = (float)kx;
+        kp.y = (float)ky;
+        if (level != 0) {
+            kp.x = __fmul_rn(kp.x, L.scale);
+            kp.y = __fmul_rn(kp.y, L.scale);
+        }
+        kp.size = (float)L.scaled_patch;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kps[(size_t)frame * g->kcap + slot] = kp;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K7: Hamming best / second best.  Lane = one query descriptor (8 dwords in VGPRs); the   */
+/* train descriptor of an iteration is wave-uniform, so its 8 dwords arrive by scalar      */
+/* loads and feed v_xor / v_bcnt (popcount-accumulate) as SGPR operands: 16 VALU per pair  */
+/* + 4 to keep the two smallest keys.  key = distance << 16 | local train index: the       */
+/* minimum key is the best distance with the LOWEST index, the second-smallest key carries */
+/* the second-best distance (DESIGN.md "match").  A block = 64 queries x one train chunk,   */
+/* its 4 waves take quarter-chunks and merge through LDS.                                  */
+/* ------------------------------------------------------------------------------------ */
+struct match_partial {
+    uint16_t d1, d2;
+    int32_t j1;
+};
+
+__device__ __forceinline__ void merge_partial(int &d1, int &j1, int &d2, int e1, int ej, int e2)
+{
+    /* (d1, j1, d2) covers lower train indices than (e1, ej, e2); ties keep the lower */
+    if (e1 < d1) {
+        d2 = imin(d1, e2);
+        d1 = e1;
+        j1 = ej;
+    } else {
+        d2 = imin(d2, e1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
+                                               const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
+                                               int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
+                                               int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
+                                               int th, int rnum, int rden, int out_stride,
+                                               match_partial *__restrict__ partial, int32_t *__restrict__ idx_out,
+                                               uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+{
+    __shared__ int s_d1[4][64], s_j1[4][64], s_d2[4][64];
+    const int frame = blockIdx.z, chunk = blockIdx.y;
+    /* batch mode: train = frame + shift (clamped to 0); exclude j == i when train == query frame */
+    int tframe = frame + train_frame_shift;
+    if (tframe < 0) tframe = 0;
+    const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[tframe] : nt_fixed;
+    const bool excl = exclude_self_mode == 1 || (exclude_self_mode == 2 && tframe == frame);
+    const uint32_t *qf = query + (size_t)frame * q_frame_stride;
+    const uint32_t *tf = train + (size_t)tframe * t_frame_stride;
+    const int lane = lane_id();
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int qi = blockIdx.x * 64 + lane;
+    const bool qvalid = qi < nq;
+
+    uint32_t qw[8];
+    {
+        const uint4 *p = (const uint4 *)(qf + (size_t)(qvalid ? qi : 0) * 8);
+        const uint4 lo = p[0], hi = p[1];
+        qw[0] = lo.x; qw[1] = lo.y; qw[2] = lo.z; qw[3] = lo.w;
+        qw[4] = hi.x; qw[5] = hi.y; qw[6] = hi.z; qw[7] = hi.w;
+    }
+    const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
+    const int quarter = (imax(c1 - c0, 0) + 3) >> 2;
+    const int t0 = imin(c0 + wave * quarter, c1), t1 = imin(t0 + quarter, c1);
+
+    uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    for (int j = t0; j < t1; j++) {
+        const uint32_t *tj = tf + (size_t)j * 8;
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
+        uint32_t key = (d << 16) | (uint32_t)(j - t0);
+        if (excl && j == qi) key = 0xFFFFFFFFu;
+        k2 = min(k2, max(k1, key));
+        k1 = min(k1, key);
+    }
+    int d1 = (int)(k1 >> 16), d2 = (int)(k2 >> 16);
+    int j1 = d1 == 0xFFFF ? -1 : t0 + (int)(k1 & 0xFFFF);
+    s_d1[wave][lane] = d1;
+    s_j1[wave][lane] = j1;
+    s_d2[wave][lane] = d2;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int wv = 1; wv < 4; wv++) merge_partial(d1, j1, d2, s_d1[wv][lane], s_j1[wv][lane], s_d2[wv][lane]);
+    if (n_chunks > 1) {
+        if (qi < out_stride) {
+            match_partial mp;
+            mp.d1 = (uint16_t)d1;
+            mp.d2 = (uint16_t)d2;
+            mp.j1 = j1;
+            partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
+        }
+        return;
+    }
+    if (qi < out_stride) {
+        const size_t o = (size_t)frame * out_stride + qi;
+        const bool ok = qvalid && j1 >= 0 && d1 <= th && d1 * rden < d2 * rnum;
+        idx_out[o] = ok ? j1 : -1;
+        d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+        d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_match_merge(const match_partial *__restrict__ partial, const int32_t *__restrict__ nq_arr,
+                                                     int nq_fixed, int n_chunks, int th, int rnum, int rden, int out_stride,
+                                                     int32_t *__restrict__ idx_out, uint16_t *__restrict__ d1_out,
+                                                     uint16_t *__restrict__ d2_out)
+{
+    const int frame = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= out_stride) return;
+    const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
+    int d1 = 0xFFFF, d2 = 0xFFFF, j1 = -1;
+    for (int c = 0; c < n_chunks; c++) {
+        const match_partial mp = partial[((size_t)frame * n_chunks + c) * out_stride + qi];
+        merge_partial(d1, j1, d2, mp.d1, mp.j1, mp.d2);
+    }
+    const size_t o = (size_t)frame * out_stride + qi;
+    const bool qvalid = qi < nq;
+    const bool ok = qvalid && j1 >= 0 && d1 <= th && d1 * rden < d2 * rnum;
+    idx_out[o] = ok ? j1 : -1;
+    d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+    d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------------------------ */
+/* launch wrappers (host)                                                                */
+/* ------------------------------------------------------------------------------------ */
+void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride, int64_t frame_stride,
+                int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames)
+{
+    dim3 grid((hg.lv[0].w + 255) / 256, (hg.lv[0].h + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, (const uint8_t *)src, channels, row_stride, frame_stride,
+                       c0, c1, c2, pyr, dg);
+}
+
+void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
+                int level, int n_frames)
+{
+    dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level);
+}
+
+void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
+                    const uint32_t *tiles, int n_frames)
+{
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles);
+}
+
+void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+              const uint32_t *tiles, int n_frames)
+{
+    hipLaunchKernelGGL(k_blur, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, blur, dg, tiles);
+}
+
+void ssk_cells(hipStream_t s, bool emit, const uint8_t *score, const ss_geom *dg, const ss_geom &hg,
+               int32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames)
+{
+    if (emit)
+        hipLaunchKernelGGL(k_cells<true>, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, dg, cell_cnt, cand, state);
+    else
+        hipLaunchKernelGGL(k_cells<false>, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, dg, cell_cnt, cand, state);
+}
+
+void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
+                  uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state, int n_frames)
+{
+    hipLaunchKernelGGL(k_quadtree, dim3(hg.n_levels, n_frames), dim3(64), 0, s, dg, cand, qbuf0, qbuf1, nodes, lists,
+                       sel, state);
+}
+
+void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_level_state *state, uint32_t *kp_ref,
+               int32_t *n_kp, int32_t *level_counts, int32_t *frame_error, int n_frames)
+{
+    hipLaunchKernelGGL(k_slots, dim3(n_frames), dim3(64), 0, s, dg, sel, state, kp_ref, n_kp, level_counts, frame_error);
+}
+
+void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
+                         const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
+                         uint8_t *desc, int n_frames)
+{
+    hipLaunchKernelGGL(k_orient_describe, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
+                       n_kp, kps, desc);
+}
+
+int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len)
+{
+    const int q_groups = (n_query_max + 63) / 64;
+    const long blocks_wanted = 2048; /* >> 256 CUs */
+    long chunks = (blocks_wanted + (long)q_groups * n_frames - 1) / ((long)q_groups * n_frames > 0 ? (long)q_groups * n_frames : 1);
+    const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave */
+    if (chunks > max_chunks) chunks = max_chunks;
+    const long min_chunks = ((long)n_train_max + 4 * 32768 - 1) / (4 * 32768); /* 16-bit local index */
+    if (chunks < min_chunks) chunks = min_chunks;
+    if (chunks < 1) chunks = 1;
+    int len = (int)(((long)n_train_max + chunks - 1) / chunks);
+    len = (len + 3) & ~3;
+    if (len < 4) len = 4;
+    *chunk_len = len;
+    return (int)(((long)n_train_max + len - 1) / len > 0 ? ((long)n_train_max + len - 1) / len : 1);
+}
+
+void ssk_match(hipStream_t s, const void *query, const void *train, const int32_t *nq_arr, const int32_t *nt_arr,
+               int nq_fixed, int nt_fixed, int64_t q_frame_stride_words, int64_t t_frame_stride_words,
+               int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
+               int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames)
+{
+    dim3 grid((out_stride + 63) / 64, n_chunks, n_frames);
+    hipLaunchKernelGGL(k_match, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
+                       nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
+                       n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+    if (n_chunks > 1) {
+        dim3 g2((out_stride + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, (const match_partial *)partial, nq_arr, nq_fixed,
+                           n_chunks, th, rnum, rden, out_stride, idx, d1, d2);
+    }
+}

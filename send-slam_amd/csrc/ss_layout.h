@@ -1,0 +1,96 @@
+/*
+ * ss_layout.h -- HBM layout of one extraction context, shared by host code and kernels.
+ *
+ * All per-frame buffers are [batch slot][...] so one launch covers a whole batch of frames
+ * (one camera's frame batch per GPU; BASELINE.json north_star).  Per frame:
+ *
+ *   pyr / blur / score   three identical "pyramid blocks": level l at byte offset lv[l].off,
+ *                        row pitch lv[l].pitch (multiple of 64 B -> every row starts on a
+ *                        64-B line, dword/dwordx4 row loads are aligned), no border stored
+ *                        (DESIGN.md "no stored border").
+ *   cell_cnt             one int per grid cell, all levels (cell_base + row*n_cols + col)
+ *   cand                 packed candidates, level l at cand_base, upstream order
+ *   sel                  per-level quadtree survivors, level l at sel_base, list order
+ *   qt_* scratch         quadtree ping-pong record buffers, node table, sort items
+ *   kps / desc           final keypoints and descriptors, kcap rows
+ *
+ * A candidate / record is one u32: x[0:12) | y[12:24) | response[24:32), x and y relative
+ * to the (16,16) border origin for candidates, level coordinates for `sel`.
+ */
+#ifndef SS_LAYOUT_H
+#define SS_LAYOUT_H
+
+#include <stdint.h>
+
+#define SS_MAX_LEVELS_ 16
+#define SS_TILE_W 64
+#define SS_TILE_H 16
+
+#define SS_PACK(x, y, r) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
+#define SS_PX(p) ((int)((p) & 0xFFFu))
+#define SS_PY(p) ((int)(((p) >> 12) & 0xFFFu))
+#define SS_PR(p) ((int)((p) >> 24))
+
+typedef struct {
+    int32_t w, h, pitch;
+    uint32_t off; /* byte offset inside a pyramid block */
+    /* cell grid of ComputeKeyPointsOctTree */
+    int32_t n_cols, n_rows, w_cell, h_cell;
+    int32_t cell_base;
+    int32_t quota;
+    int32_t cand_base, cand_cap;
+    int32_t sel_base, sel_cap;
+    int32_t node_base, node_cap; /* quadtree nodes */
+    int32_t item_base, item_cap; /* quadtree sort items / expandable lists */
+    /* 64x16 tiles for the image kernels */
+    int32_t tile_base, tiles_x, tiles_y;
+    /* resize tables for building THIS level from level-1 (entries of 8 bytes) */
+    int32_t xtab_off, ytab_off;
+    /* quadtree roots */
+    int32_t n_ini;
+    float hx;
+    float scale;
+    int32_t scaled_patch;
+} ss_level;
+
+typedef struct {
+    int32_t n_levels;
+    int32_t w, h;
+    int32_t ini_th, min_th;
+    int32_t lap_x0, lap_x1;
+    int32_t n_features;
+    int32_t kcap;           /* keypoint rows per frame */
+    uint32_t block_bytes;   /* one pyramid block */
+    int32_t n_cells;        /* all levels */
+    int32_t cand_total;     /* u32 per frame */
+    int32_t sel_total;
+    int32_t node_total;
+    int32_t item_total;
+    int32_t tiles_total;
+    int32_t umax[16];
+    ss_level lv[SS_MAX_LEVELS_];
+} ss_geom;
+
+/* resize table entries */
+typedef struct {
+    uint16_t s0, s1; /* source index and clamped neighbour */
+    int16_t a0, a1;  /* 11-bit fixed-point weights */
+} ss_rtab;
+
+/* quadtree node: rectangle (UL.x, UR.x, UL.y, BL.y), record segment, flags */
+typedef struct {
+    uint16_t x0, x1, y0, y1;
+    int32_t beg;
+    int32_t cnt;  /* > 0 */
+    int32_t flags; /* bit0 alive, bit1 no_more, bit2 buffer index of the segment */
+} ss_qnode;
+
+/* per-(frame, level) status words written by the kernels */
+typedef struct {
+    int32_t n_cand;
+    int32_t n_sel;
+    int32_t error; /* 0 ok; SS_ERR_OVERFLOW-style codes */
+    int32_t pad;
+} ss_level_state;
+
+#endif

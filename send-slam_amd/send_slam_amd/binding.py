@@ -1,0 +1,237 @@
+"""ctypes binding of libsendslam_orb.so (include/sendslam_orb.h).
+
+This is plumbing over the C ABI: it owns no arithmetic.  There is no fallback of any kind:
+if the shared library is missing or exports the wrong ABI, importing the symbols raises, and
+without a HIP device `OrbContext()` raises `OrbError(SS_ERR_NO_DEVICE)`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
+SS_MAX_LEVELS = 16
+ABI_VERSION = 1
+
+SS_OK = 0
+SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3, -4
+SS_ERR_OVERFLOW, SS_ERR_NOT_CALIBRATED, SS_ERR_BAD_FRAME, SS_ERR_NO_MEMORY, SS_ERR_STATE = -5, -6, -7, -8, -9
+
+EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy", "ss_last_error",
+           "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_match",
+           "ss_match_device", "ss_match_batch_device", "ss_synchronize", "ss_get_stream",
+           "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch"]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("lapping_x0", C.c_int32),
+                ("lapping_x1", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("type", C.c_char * 16), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double),
+                ("p2", C.c_double), ("width", C.c_int32), ("height", C.c_int32), ("fps", C.c_double),
+                ("rgb", C.c_int32), ("th_depth", C.c_double), ("baseline", C.c_double),
+                ("depth_map_factor", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("n_keypoints", C.c_int32), ("camera_id", C.c_int32), ("timestamp", C.c_double),
+                ("keypoints", C.c_void_p), ("descriptors", C.c_void_p),
+                ("level_counts", C.c_int32 * SS_MAX_LEVELS)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("keypoints", C.c_void_p),
+                ("descriptors", C.c_void_p), ("n_keypoints", C.c_void_p), ("level_counts", C.c_void_p)]
+
+
+class StageStats(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("mean_ms", C.c_double), ("median_ms", C.c_double), ("algorithmic_bytes", C.c_int64)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4")])
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libsendslam_orb: {message} (status {code})")
+        self.code = code
+        self.message = message
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library or raises; never substitutes anything for it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C send-slam_amd` "
+                          f"(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise ImportError(f"{LIB_PATH} does not export {name}")
+    lib.ss_last_error.restype = C.c_char_p
+    lib.ss_last_error.argtypes = [C.c_void_p]
+    lib.ss_create.argtypes = [C.c_int, C.POINTER(OrbParams), C.POINTER(C.c_void_p)]
+    lib.ss_destroy.argtypes = [C.c_void_p]
+    lib.ss_set_calibration.argtypes = [C.c_void_p, C.c_int, C.POINTER(Camera)]
+    lib.ss_extract.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_double, C.POINTER(FrameResult)]
+    lib.ss_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int64, C.c_int64]
+    lib.ss_get_batch_view.argtypes = [C.c_void_p, C.POINTER(BatchView)]
+    lib.ss_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ss_match_device.argtypes = lib.ss_match.argtypes
+    lib.ss_match_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    lib.ss_synchronize.argtypes = [C.c_void_p]
+    lib.ss_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ss_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.ss_profile_reset.argtypes = [C.c_void_p]
+    lib.ss_stats.argtypes = [C.c_void_p, C.POINTER(StageStats), C.c_int]
+    lib.ss_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    if lib.ss_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI {lib.ss_abi_version()} != {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def default_params(**kw) -> OrbParams:
+    p = OrbParams()
+    load().ss_orb_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class OrbContext:
+    """One extraction context = one HIP stream on one device (ss_create / ss_destroy)."""
+
+    def __init__(self, device: int = 0, **params):
+        self._lib = load()
+        self.params = default_params(**params)
+        h = C.c_void_p()
+        rc = self._lib.ss_create(int(device), C.byref(self.params), C.byref(h))
+        if rc != SS_OK:
+            raise OrbError(rc, (self._lib.ss_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise OrbError(rc, (self._lib.ss_last_error(self._h) or b"").decode())
+        return rc
+
+    def last_error(self) -> str:
+        return (self._lib.ss_last_error(self._h) or b"").decode()
+
+    # ---- calibration (the "calibration" message of the wire protocol) ----
+    def set_calibration(self, camera_id: int, cam: Camera):
+        self._check(self._lib.ss_set_calibration(self._h, int(camera_id), C.byref(cam)))
+
+    # ---- host in / host out ----
+    def extract(self, img: np.ndarray, camera_id: int = 1, timestamp: float = 0.0):
+        """img: (H, W) or (H, W, C) uint8.  -> (keypoints KP_DTYPE[n], desc u8[n,32], level_counts)"""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        res = FrameResult()
+        self._check(self._lib.ss_extract(self._h, int(camera_id), img.ctypes.data, w, h, ch, w * ch,
+                                         float(timestamp), C.byref(res)))
+        n = res.n_keypoints
+        kps = np.empty(n, KP_DTYPE)
+        desc = np.empty((n, 32), np.uint8)
+        if n:
+            C.memmove(kps.ctypes.data, res.keypoints, n * KP_DTYPE.itemsize)
+            C.memmove(desc.ctypes.data, res.descriptors, n * 32)
+        return kps, desc, np.array(list(res.level_counts)[:self.params.n_levels])
+
+    def match(self, q: np.ndarray, t: np.ndarray, th: int = 50, ratio_num: int = 9, ratio_den: int = 10,
+              exclude_self: bool = False):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        nq, nt = len(q), len(t)
+        idx = np.empty(nq, np.int32)
+        d1 = np.empty(nq, np.uint16)
+        d2 = np.empty(nq, np.uint16)
+        self._check(self._lib.ss_match(self._h, q.ctypes.data, nq, t.ctypes.data if nt else None, nt, int(th),
+                                       int(ratio_num), int(ratio_den), int(exclude_self), idx.ctypes.data,
+                                       d1.ctypes.data, d2.ctypes.data))
+        return idx, d1, d2
+
+    # ---- device in / device out (pointers are raw device addresses, e.g. tensor.data_ptr()) ----
+    def extract_batch_device(self, d_ptr: int, n_frames: int, width: int, height: int, channels: int = 1,
+                             row_stride: Optional[int] = None, frame_stride: Optional[int] = None):
+        row_stride = width * channels if row_stride is None else row_stride
+        frame_stride = row_stride * height if frame_stride is None else frame_stride
+        self._check(self._lib.ss_extract_batch_device(self._h, C.c_void_p(d_ptr), n_frames, width, height,
+                                                      channels, row_stride, frame_stride))
+
+    def batch_view(self) -> BatchView:
+        v = BatchView()
+        self._check(self._lib.ss_get_batch_view(self._h, C.byref(v)))
+        return v
+
+    def match_device(self, d_q: int, nq: int, d_t: int, nt: int, d_idx: int, d_d1: int, d_d2: int, th: int = 50,
+                     ratio_num: int = 9, ratio_den: int = 10, exclude_self: bool = False):
+        self._check(self._lib.ss_match_device(self._h, C.c_void_p(d_q), nq, C.c_void_p(d_t), nt, th, ratio_num,
+                                              ratio_den, int(exclude_self), C.c_void_p(d_idx), C.c_void_p(d_d1),
+                                              C.c_void_p(d_d2)))
+
+    def match_batch_device(self, mode: int, d_idx: int, d_d1: int, d_d2: int, th: int = 50, ratio_num: int = 9,
+                           ratio_den: int = 10):
+        self._check(self._lib.ss_match_batch_device(self._h, mode, th, ratio_num, ratio_den, C.c_void_p(d_idx),
+                                                    C.c_void_p(d_d1), C.c_void_p(d_d2)))
+
+    def synchronize(self):
+        self._check(self._lib.ss_synchronize(self._h))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self._check(self._lib.ss_get_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def profile(self, on: bool):
+        self._check(self._lib.ss_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.ss_profile_reset(self._h))
+
+    def stats(self):
+        arr = (StageStats * 32)()
+        n = self._check(self._lib.ss_stats(self._h, arr, 32))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms,
+                     mean_ms=arr[i].mean_ms, median_ms=arr[i].median_ms,
+                     algorithmic_bytes=arr[i].algorithmic_bytes) for i in range(min(n, 32))]
+
+    def debug_fetch(self, what: int, frame: int, level: int, shape, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        n = self._check(self._lib.ss_debug_fetch(self._h, what, frame, level, out.ctypes.data, out.nbytes))
+        return out.reshape(-1)[: n // out.itemsize]
