@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of ORB extract + self-match on synthetic 1280x720 frames, 2000 kp/frame
+(BASELINE.json metric, config "1xMI355X: synthetic 1280x720 frames, ORB extract + self-match").
+
+A "step" is one pass of the hot path over ONE BATCH of frames already resident in HBM:
+ss_extract_batch_device (pyramid, FAST + NMS, quadtree, orientation, blur, rBRIEF) followed by
+ss_match_batch_device (self-match, j == i excluded).  With N GPUs every rank runs the same step
+on its own camera batch (cameras shard one per GPU, no data-path collective): weak scaling,
+value = frames all ranks processed / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel: ALGORITHMIC bytes per launch / HIP-event mean duration,
+                measured on the context's own stream inside the timed region
+  kernels       the same for every stage
+  cpu_baseline  the CPU oracle (a port: the reference's ORB-SLAM3 cannot be built here,
+                DESIGN.md) timed on this host on a bounded sample of the same frames, 1 thread
+                like the reference shim (orbslam3_mono_networked.cc:594), plus all cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "send-slam_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def make_frames(rank, batch, w, h):
+    """batch frames = ceil(batch/8) scenes x 8 time steps (consecutive frames move by (3,-2) px)."""
+    from send_slam_amd import synth
+    out = np.empty((batch, h, w), np.uint8)
+    n_scenes = (batch + 7) // 8
+    i = 0
+    for s in range(n_scenes):
+        seed = 1000 * rank + s
+        sc = synth.scene(seed, w, h)
+        for t in range(8):
+            if i >= batch:
+                break
+            out[i] = synth.frame_from_scene(sc, seed, w, h, t)
+            i += 1
+    return out
+
+
+def _cpu_one(args):
+    from oracle import orb_oracle as O
+    frame, nf = args
+    p = O.default_params(n_features=nf)
+    t0 = time.perf_counter()
+    kps, desc, _ = O.extract(frame, p)
+    idx, d1, d2 = O.match(desc, desc, 50, 9, 10, exclude_self=True)
+    return time.perf_counter() - t0, kps, desc, idx, d1, d2
+
+
+def cpu_baseline(frames, nf, budget_s=12.0):
+    """Oracle timed on host cores BEFORE the GPU is touched (a process pool forks).
+    Returns the JSON object and the per-frame oracle outputs for the parity spot-check."""
+    import multiprocessing as mp
+    from oracle import orb_oracle as O
+    O.build()
+    times, outs = [], []
+    _cpu_one((frames[0], nf))  # warm-up (page in, first malloc)
+    t_start = time.perf_counter()
+    for i in range(len(frames)):
+        r = _cpu_one((frames[i], nf))
+        times.append(r[0])
+        outs.append(r[1:])
+        if time.perf_counter() - t_start > budget_s / 2 and len(times) >= 5:
+            break
+    times.sort()
+    median = times[len(times) // 2]  # the shim's median rule (orbslam3_mono_networked.cc:661)
+    cores = len(os.sched_getaffinity(0))
+    all_cores = None
+    if cores > 1:
+        n_jobs = min(len(frames), max(cores, int(cores * (budget_s / 2) / max(median, 1e-3))))
+        n_jobs = min(n_jobs, 4 * cores)
+        jobs = [(frames[i % len(frames)], nf) for i in range(n_jobs)]
+        with mp.get_context("fork").Pool(cores) as pool:
+            t0 = time.perf_counter()
+            pool.map(_cpu_one, jobs, chunksize=1)
+            all_cores = n_jobs / (time.perf_counter() - t0)
+    obj = {"value": round(1.0 / median, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{len(times)} of the bench's own 1280x720 frames, extract + self-match, median per frame "
+                     f"{median * 1e3:.1f} ms, 1 thread (oracle/orb_oracle.c, -O3)",
+           "all_cores_value": None if all_cores is None else round(all_cores, 2), "all_cores": cores}
+    return obj, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    w, h, nf, B = a.width, a.height, a.features, a.batch
+
+    frames = make_frames(rank, B, w, h)
+
+    cpu_obj, cpu_outs = None, []
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        cpu_obj, cpu_outs = cpu_baseline(frames, nf)  # before any HIP call in this process
+
+    import torch
+    import torch.distributed as dist
+    from send_slam_amd import binding
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = binding.OrbContext(local_rank, n_features=nf, max_batch=B)
+    d_frames = torch.from_numpy(frames).to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+        ctx.match_batch_device(0, d_idx.data_ptr(), d_d1.data_ptr(), d_d2.data_ptr())
+
+    # shape the outputs once (kp_capacity is known after the first extraction)
+    ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+    ctx.synchronize()
+    view = ctx.batch_view()
+    kcap = view.kp_capacity
+    d_idx = torch.empty((B, kcap), dtype=torch.int32, device=dev)
+    d_d1 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
+    d_d2 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.synchronize()
+
+    ctx.profile(True)
+    ctx.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    ctx.synchronize()  # drains the context's stream and checks the per-frame error words
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = ctx.stats()
+
+    # parity spot-check of the measured configuration against the oracle outputs of the baseline leg
+    parity = None
+    if cpu_outs:
+        idx = d_idx.cpu().numpy()
+        parity = True
+        for b, (okps, odesc, oidx, od1, od2) in enumerate(cpu_outs):
+            kps_b, desc_b, _ = ctx.fetch_frame(b)
+            n = len(kps_b)
+            parity &= n == len(okps) and kps_b.tobytes() == okps.tobytes()
+            parity &= bool(np.array_equal(desc_b, odesc)) and bool(np.array_equal(idx[b, :n], oidx))
+        if not parity:
+            sys.exit("bench.py: GPU results differ from the oracle on the benchmark frames")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    kernels = []
+    for s in stats:
+        if s["launches"] == 0:
+            continue
+        gbs = s["algorithmic_bytes"] / (s["mean_ms"] * 1e-3) / 1e9 if s["mean_ms"] > 0 and s["algorithmic_bytes"] else None
+        kernels.append({"name": s["name"], "launches_per_step": s["launches"] / a.steps, "mean_ms": round(s["mean_ms"], 5),
+                        "total_ms": round(s["total_ms"], 3), "algorithmic_bytes_per_launch": s["algorithmic_bytes"],
+                        "achieved_GBps": None if gbs is None else round(gbs, 1)})
+    with_bytes = [k for k in kernels if k["achieved_GBps"] is not None]
+    dom = max(with_bytes, key=lambda k: k["total_ms"]) if with_bytes else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if dom and os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        key = f"{dom['name']}@batch{B}_{w}x{h}_n{nf}"
+        traffic = tj.get(key)
+    roofline = None
+    if dom:
+        roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic}
+
+    total_frames = B * a.steps * world
+    out = {
+        "metric": "frames/sec ORB extract+match @1280x720, 2000 kp/frame",
+        "value": round(total_frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"1xMI355X: synthetic {w}x{h} frames, ORB extract + self-match, {nf} kp/frame",
+                   "frames_per_step_per_gpu": B, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
+                   "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
+                   "parallelism": f"one camera batch per GPU x {world}, no collective"},
+        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

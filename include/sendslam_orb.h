@@ -145,6 +145,9 @@ int ss_extract_batch_device(ss_ctx *ctx, const void *d_pix, int n_frames, int wi
                             int height, int channels, int64_t row_stride,
                             int64_t frame_stride);
 int ss_get_batch_view(ss_ctx *ctx, ss_batch_view *out);
+/* Copies frame `frame` of the last batch to the context's host arrays (same ownership
+ * rule as ss_extract); synchronises the context's stream. */
+int ss_fetch_frame(ss_ctx *ctx, int frame, ss_frame_result *out);
 
 /* K7.  idx[i] = index of the accepted best train descriptor or -1; d1/d2 = best and
  * second-best distance (0xFFFF when absent).  Accept iff d1 <= th and d1*ratio_den <

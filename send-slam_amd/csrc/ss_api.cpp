@@ -472,6 +472,31 @@ int ss_get_batch_view(ss_ctx *c, ss_batch_view *out)
     return SS_OK;
 }
 
+int ss_fetch_frame(ss_ctx *c, int frame, ss_frame_result *out)
+{
+    if (!c || !out) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->have_geom || frame < 0 || frame >= c->last_n_frames) return fail(c, SS_ERR_STATE, "ss_fetch_frame: no such frame");
+    int rc = check_frame_errors(c);
+    if (rc != SS_OK) return rc;
+    const int kcap = c->hg.kcap;
+    int32_t nk = 0;
+    HIP_TRY(c, hipMemcpy(&nk, c->n_kp + frame, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out->level_counts, c->level_counts + (size_t)frame * SS_MAX_LEVELS, SS_MAX_LEVELS * sizeof(int32_t), hipMemcpyDeviceToHost));
+    c->h_kps.resize((size_t)std::max(nk, 1));
+    c->h_desc.resize((size_t)std::max(nk, 1) * SS_DESC_BYTES);
+    if (nk > 0) {
+        HIP_TRY(c, hipMemcpy(c->h_kps.data(), c->kps + (size_t)frame * kcap, (size_t)nk * sizeof(ss_keypoint), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(c->h_desc.data(), c->desc + (size_t)frame * kcap * SS_DESC_BYTES, (size_t)nk * SS_DESC_BYTES, hipMemcpyDeviceToHost));
+    }
+    out->n_keypoints = nk;
+    out->camera_id = c->cam_id;
+    out->timestamp = 0.0;
+    out->keypoints = c->h_kps.data();
+    out->descriptors = c->h_desc.data();
+    return SS_OK;
+}
+
 int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_train, int n_train, int th,
                     int ratio_num, int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2)
 {

@@ -22,7 +22,7 @@ SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3,
 SS_ERR_OVERFLOW, SS_ERR_NOT_CALIBRATED, SS_ERR_BAD_FRAME, SS_ERR_NO_MEMORY, SS_ERR_STATE = -5, -6, -7, -8, -9
 
 EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy", "ss_last_error",
-           "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_match",
+           "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_fetch_frame", "ss_match",
            "ss_match_device", "ss_match_batch_device", "ss_synchronize", "ss_get_stream",
            "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch"]
 
@@ -79,6 +79,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C send-slam_amd` "
                           f"(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.so.7 and a
+    # second copy (from /opt/rocm) cannot initialise the device after the first has.  Loading
+    # torch first makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to torch's copy,
+    # so device pointers, streams and RCCL buffers are shared.  Without torch installed the
+    # library simply uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):
@@ -93,6 +102,7 @@ def load():
     lib.ss_extract_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int64, C.c_int64]
     lib.ss_get_batch_view.argtypes = [C.c_void_p, C.POINTER(BatchView)]
+    lib.ss_fetch_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(FrameResult)]
     lib.ss_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ss_match_device.argtypes = lib.ss_match.argtypes
@@ -198,6 +208,18 @@ class OrbContext:
         v = BatchView()
         self._check(self._lib.ss_get_batch_view(self._h, C.byref(v)))
         return v
+
+    def fetch_frame(self, frame: int):
+        """Host copy of one frame of the last batch -> (keypoints, desc, level_counts)."""
+        res = FrameResult()
+        self._check(self._lib.ss_fetch_frame(self._h, int(frame), C.byref(res)))
+        n = res.n_keypoints
+        kps = np.empty(n, KP_DTYPE)
+        desc = np.empty((n, 32), np.uint8)
+        if n:
+            C.memmove(kps.ctypes.data, res.keypoints, n * KP_DTYPE.itemsize)
+            C.memmove(desc.ctypes.data, res.descriptors, n * 32)
+        return kps, desc, np.array(list(res.level_counts)[:self.params.n_levels])
 
     def match_device(self, d_q: int, nq: int, d_t: int, nt: int, d_idx: int, d_d1: int, d_d2: int, th: int = 50,
                      ratio_num: int = 9, ratio_den: int = 10, exclude_self: bool = False):

@@ -71,15 +71,17 @@ def test_golden_consecutive_frame_match():
     assert np.array_equal(idx, b["prev_idx"]) and np.array_equal(d1, b["prev_d1"]) and np.array_equal(d2, b["prev_d2"])
 
 
-@pytest.mark.parametrize("seed,w,h,nf", [(3, 640, 480, 1250), (4, 1280, 720, 2000), (5, 333, 517, 700),
-                                         (6, 1920, 1080, 2000), (7, 131, 99, 300), (8, 640, 480, 6250)])
-def test_extract_bit_exact_vs_oracle(oracle, seed, w, h, nf):
+@pytest.mark.parametrize("seed,w,h,nf,nl", [(3, 640, 480, 1250, 8), (4, 1280, 720, 2000, 8), (5, 333, 517, 700, 8),
+                                            (6, 1920, 1080, 2000, 8), (7, 323, 243, 300, 8), (8, 640, 480, 6250, 8),
+                                            (9, 131, 99, 200, 3), (10, 640, 480, 40, 8), (11, 800, 600, 1000, 1)])
+def test_extract_bit_exact_vs_oracle(oracle, seed, w, h, nf, nl):
     # 640x480/1250 = config 1 of BASELINE.json, 1280x720/2000 = the metric config,
-    # 1920x1080 = config 4; 6250 = the 5 x nFeatures extractor of monocular initialisation
+    # 1920x1080 = config 4; 6250 = the 5 x nFeatures extractor of monocular initialisation;
+    # 243 px high is the smallest image 8 levels admit; 40 features gives per-level quotas of 4..9
     img = synth.frame(seed, w, h)
-    with binding.OrbContext(0, n_features=nf) as ctx:
+    with binding.OrbContext(0, n_features=nf, n_levels=nl) as ctx:
         kps, desc, counts = ctx.extract(img)
-    okps, odesc, ocounts = oracle.extract(img, oracle.default_params(n_features=nf))
+    okps, odesc, ocounts = oracle.extract(img, oracle.default_params(n_features=nf, n_levels=nl))
     assert np.array_equal(counts, ocounts)
     assert len(kps) == len(okps)
     for f in ("octave", "response", "x", "y", "size", "angle"):
@@ -198,23 +200,16 @@ def test_batch_device_path_matches_single_frame_path(oracle):
             ctx.synchronize()
             res[mode] = (idx.cpu().numpy().copy(), d1.cpu().numpy().view(np.uint16).copy(),
                          d2.cpu().numpy().view(np.uint16).copy())
-        import ctypes as C
-        n_kp = np.empty(B, np.int32)
-        kps = np.empty((B, kcap), binding.KP_DTYPE)
-        desc = np.empty((B, kcap, 32), np.uint8)
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        assert hip.hipMemcpy(n_kp.ctypes.data, v.n_keypoints, n_kp.nbytes, 2) == 0
-        assert hip.hipMemcpy(kps.ctypes.data, v.keypoints, kps.nbytes, 2) == 0
-        assert hip.hipMemcpy(desc.ctypes.data, v.descriptors, desc.nbytes, 2) == 0
+        fetched = [ctx.fetch_frame(b) for b in range(B)]
     p = oracle.default_params(n_features=nf)
     prev = None
     for b in range(B):
-        okps, odesc, _ = oracle.extract(frames[b], p)
-        n = n_kp[b]
-        assert n == len(okps)
-        assert kps[b, :n].tobytes() == okps.tobytes()
-        assert np.array_equal(desc[b, :n], odesc)
+        okps, odesc, ocounts = oracle.extract(frames[b], p)
+        kps_b, desc_b, counts_b = fetched[b]
+        n = len(kps_b)
+        assert n == len(okps) and np.array_equal(counts_b, ocounts)
+        assert kps_b.tobytes() == okps.tobytes()
+        assert np.array_equal(desc_b, odesc)
         want = oracle.match(odesc, odesc, exclude_self=True)
         for a, bb in zip(res[0], want):
             assert np.array_equal(a[b, :n], bb)
