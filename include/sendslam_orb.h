@@ -151,7 +151,9 @@ int ss_fetch_frame(ss_ctx *ctx, int frame, ss_frame_result *out);
 
 /* K7.  idx[i] = index of the accepted best train descriptor or -1; d1/d2 = best and
  * second-best distance (0xFFFF when absent).  Accept iff d1 <= th and d1*ratio_den <
- * d2*ratio_num.  exclude_self skips j == i.  Ties: lowest index. */
+ * d2*ratio_num.  exclude_self skips j == i.  Ties: lowest index.  th < 0 = raw mode: no
+ * acceptance test, idx = best index (or -1 when there is no train row): what a shard of a
+ * partitioned database reports before the cross-shard merge. */
 int ss_match(ss_ctx *ctx, const uint8_t *query, int n_query, const uint8_t *train,
              int n_train, int th, int ratio_num, int ratio_den, int exclude_self,
              int32_t *idx, uint16_t *d1, uint16_t *d2);

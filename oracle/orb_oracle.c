@@ -883,6 +883,6 @@ void orc_match(const uint8_t *q, int nq, const uint8_t *t, int nt, int th, int r
         d1[i] = (uint16_t)best;
         d2[i] = (uint16_t)second;
         /* accept iff d1 <= TH and d1 < ratio*d2, integer form d1*den < d2*num */
-        idx[i] = (best_j >= 0 && best <= th && best * ratio_den < second * ratio_num) ? best_j : -1;
+        idx[i] = (best_j >= 0 && (th < 0 || (best <= th && best * ratio_den < second * ratio_num))) ? best_j : -1;
     }
 }

@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     }
     if (qi < out_stride) {
         const size_t o = (size_t)frame * out_stride + qi;
-        const bool ok = qvalid && j1 >= 0 && d1 <= th && d1 * rden < d2 * rnum;
+        const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
         idx_out[o] = ok ? j1 : -1;
         d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
         d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
     }
     const size_t o = (size_t)frame * out_stride + qi;
     const bool qvalid = qi < nq;
-    const bool ok = qvalid && j1 >= 0 && d1 <= th && d1 * rden < d2 * rnum;
+    const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
     idx_out[o] = ok ? j1 : -1;
     d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
     d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;

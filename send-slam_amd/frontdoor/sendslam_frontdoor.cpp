@@ -1,0 +1,539 @@
+/*
+ * sendslam_frontdoor.cpp -- stand-in for the reference's containerised backend shim
+ * (/root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc, 684 lines): same
+ * environment variable, same TCP client role, same length-prefixed MessagePack protocol, same
+ * guards and log-and-skip policy, same shutdown summary -- with ORB_SLAM3::System replaced by
+ * libsendslam_orb.so (HIP kernels on an MI355X).  The Elixir side (SlamHandler,
+ * send_slam/lib/send_slam/slam_handler.ex) needs no change to talk to it.
+ *
+ * Mapping to the reference:
+ *   ParseMessage / MessagePacket            :78-88, :284-339   -> parse_message
+ *   ParseCameraCalibration / RequireScalar  :90-156            -> parse_calibration
+ *   BuildCalibrationYaml (ORB literals)     :158-223           -> settings_text (for logs) +
+ *                                                                 ss_orb_params / ss_camera
+ *   main: env, connect, framing, guards     :341-627           -> main
+ *   cv::imdecode(IMREAD_UNCHANGED) on PNM   :546               -> decode_pnm (P5 -> 1 channel,
+ *                                                                 P6 -> 3 channels in BGR order)
+ *   TrackMonocular                          :594               -> ss_extract + ss_match against
+ *                                                                 the previous frame
+ *   SendPosePacket                          :225-282           -> send_pose_packet (emitted only
+ *                                                                 when tracking_state == OK, :596;
+ *                                                                 pose estimation itself is the
+ *                                                                 next step)
+ *   pacing sleep, timing summary            :618-624, :656-664 -> same
+ *
+ * Extras, all off by default so the binary stays a strict drop-in:
+ *   SENDSLAM_EMIT_FEATURES=1   after every frame send {"type":"features", ...} (the reference
+ *                              host logs unknown types at debug level and ignores them,
+ *                              slam_handler.ex:131-132)
+ *   SENDSLAM_ORB_NFEATURES=n   override the 1250 literal (BASELINE.json benches use 2000)
+ *   SENDSLAM_DEVICE=k          HIP device ordinal (one backend process per GPU / camera)
+ *   --selftest-pose            print the pose packet for fixed values as hex and exit (golden
+ *                              wire bytes, tests/test_wire.py; needs no GPU)
+ */
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sendslam_orb.h"
+#include "ss_msgpack.h"
+
+using namespace std;
+
+namespace {
+
+/* ORB_SLAM3::Tracking::eTrackingState */
+enum tracking_state { SYSTEM_NOT_READY = -1, NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, TRACKING_OK = 2, RECENTLY_LOST = 3, LOST = 4 };
+
+struct CameraCalibration {
+    string type;
+    double fx = 0, fy = 0, cx = 0, cy = 0, k1 = 0, k2 = 0, p1 = 0, p2 = 0;
+    int width = 0, height = 0;
+    double fps = 0;
+    int rgb = 0;
+    double stereoThDepth = 0, stereoBaseline = 0, depthMapFactor = 0;
+};
+
+struct MessagePacket {
+    string type;
+    const uint8_t *imageData = nullptr; /* view into the payload (the reference copies, :325) */
+    size_t imageSize = 0;
+    double timestamp = 0.0;
+    bool hasImage = false, hasTimestamp = false;
+    int camera_id = 0;
+    bool hasCalibrationParameters = false;
+    CameraCalibration calibrationParameters;
+};
+
+template <typename F> auto require_scalar(const ssmp::value &node, const string &section, const char *key, F conv)
+{
+    const ssmp::value *v = node.find(key);
+    if (!v) throw runtime_error("Calibration section '" + section + "' is missing key '" + key + "'");
+    try {
+        return conv(*v);
+    } catch (const exception &ex) {
+        throw runtime_error("Failed to parse key '" + section + "." + key + "': " + string(ex.what()));
+    }
+}
+
+CameraCalibration parse_camera_calibration(const ssmp::value &obj)
+{
+    if (obj.t != ssmp::type::MAP) throw runtime_error("Calibration 'camera' field must be a map");
+    auto D = [](const ssmp::value &v) { return v.as_double(); };
+    auto I = [](const ssmp::value &v) { return v.as_int(); };
+    auto S = [](const ssmp::value &v) { return v.as_string(); };
+    CameraCalibration c;
+    c.type = require_scalar(obj, "camera", "type", S);
+    c.fx = require_scalar(obj, "camera", "fx", D);
+    c.fy = require_scalar(obj, "camera", "fy", D);
+    c.cx = require_scalar(obj, "camera", "cx", D);
+    c.cy = require_scalar(obj, "camera", "cy", D);
+    c.k1 = require_scalar(obj, "camera", "k1", D);
+    c.k2 = require_scalar(obj, "camera", "k2", D);
+    c.p1 = require_scalar(obj, "camera", "p1", D);
+    c.p2 = require_scalar(obj, "camera", "p2", D);
+    c.width = require_scalar(obj, "camera", "width", I);
+    c.height = require_scalar(obj, "camera", "height", I);
+    c.fps = require_scalar(obj, "camera", "fps", D);
+    c.rgb = require_scalar(obj, "camera", "rgb", I);
+    c.stereoThDepth = require_scalar(obj, "camera", "th_depth", D);
+    c.stereoBaseline = require_scalar(obj, "camera", "baseline", D);
+    c.depthMapFactor = require_scalar(obj, "camera", "depth_map_factor", D);
+    return c;
+}
+
+CameraCalibration parse_calibration(const ssmp::value &obj)
+{
+    if (obj.t != ssmp::type::MAP) throw runtime_error("Calibration payload must be a map");
+    if (const ssmp::value *cam = obj.find("camera")) return parse_camera_calibration(*cam);
+    return parse_camera_calibration(obj);
+}
+
+bool parse_message(const ssmp::value &root, MessagePacket &packet)
+{
+    if (root.t != ssmp::type::MAP) throw runtime_error("MessagePack payload must be a map at the top level");
+    for (const auto &kv : root.map) {
+        const string key = kv.first.as_string();
+        const ssmp::value &value = kv.second;
+        if (key == "type") packet.type = value.as_string();
+        else if (key == "calibration" || key == "calibration_params") {
+            packet.calibrationParameters = parse_calibration(value);
+            packet.hasCalibrationParameters = true;
+        } else if (key == "timestamp") {
+            packet.timestamp = value.as_double();
+            packet.hasTimestamp = true;
+        } else if (key == "image" || key == "frame") {
+            if (value.t != ssmp::type::BIN) throw runtime_error("Image data must be encoded as MessagePack bin");
+            packet.imageData = value.data;
+            packet.imageSize = value.size;
+            packet.hasImage = true;
+        } else if (key == "camera_id") packet.camera_id = value.as_int();
+        /* other fields are ignored (:332-335) */
+    }
+    return !packet.type.empty();
+}
+
+/* What BuildCalibrationYaml would have written; logged, not parsed */
+string settings_text(const CameraCalibration &c, const ss_orb_params &p)
+{
+    ostringstream o;
+    o << "Camera.type: \"" << c.type << "\"\n"
+      << "Camera1.fx: " << c.fx << "\nCamera1.fy: " << c.fy << "\nCamera1.cx: " << c.cx << "\nCamera1.cy: " << c.cy << "\n"
+      << "Camera1.k1: " << c.k1 << "\nCamera1.k2: " << c.k2 << "\nCamera1.p1: " << c.p1 << "\nCamera1.p2: " << c.p2 << "\n"
+      << "Camera.width: " << c.width << "\nCamera.height: " << c.height << "\nCamera.fps: " << c.fps << "\n"
+      << "Camera.RGB: " << c.rgb << "\nStereo.ThDepth: " << c.stereoThDepth << "\nStereo.b: " << c.stereoBaseline << "\n"
+      << "RGBD.DepthMapFactor: " << c.depthMapFactor << "\n"
+      << "ORBextractor.nFeatures: " << p.n_features << "\nORBextractor.scaleFactor: " << p.scale_factor << "\n"
+      << "ORBextractor.nLevels: " << p.n_levels << "\nORBextractor.iniThFAST: " << p.ini_th_fast << "\n"
+      << "ORBextractor.minThFAST: " << p.min_th_fast << "\n";
+    return o.str();
+}
+
+/* cv::imdecode(IMREAD_UNCHANGED) for the two encodings the host sends (PPM from
+ * Evision.imencode(".ppm"), slam_handler.ex:275-281; PGM for gray frames).  Returns false
+ * if the buffer is not a binary 8-bit PNM ("Failed to decode frame image data.", :547-551). */
+bool decode_pnm(const uint8_t *p, size_t n, int &w, int &h, int &channels, vector<uint8_t> &pix)
+{
+    size_t i = 0;
+    auto token = [&](long &out) -> bool {
+        for (;;) {
+            while (i < n && isspace(p[i])) i++;
+            if (i < n && p[i] == '#') {
+                while (i < n && p[i] != '\n') i++;
+                continue;
+            }
+            break;
+        }
+        if (i >= n || !isdigit(p[i])) return false;
+        long v = 0;
+        while (i < n && isdigit(p[i])) {
+            v = v * 10 + (p[i] - '0');
+            if (v > 100000000) return false;
+            i++;
+        }
+        out = v;
+        return true;
+    };
+    if (n < 7 || p[0] != 'P' || (p[1] != '5' && p[1] != '6')) return false;
+    channels = p[1] == '6' ? 3 : 1;
+    i = 2;
+    long lw, lh, maxv;
+    if (!token(lw) || !token(lh) || !token(maxv)) return false;
+    if (lw <= 0 || lh <= 0 || lw > 16384 || lh > 16384 || maxv <= 0 || maxv > 255) return false;
+    if (i >= n || !isspace(p[i])) return false;
+    i++; /* single whitespace after maxval */
+    const size_t need = (size_t)lw * lh * channels;
+    if (n - i < need) return false;
+    w = (int)lw;
+    h = (int)lh;
+    pix.resize(need);
+    if (channels == 1) memcpy(pix.data(), p + i, need);
+    else
+        for (size_t k = 0; k < need; k += 3) { /* PPM stores R,G,B; a cv::Mat is B,G,R */
+            pix[k] = p[i + k + 2];
+            pix[k + 1] = p[i + k + 1];
+            pix[k + 2] = p[i + k];
+        }
+    return true;
+}
+
+struct pose {
+    double px, py, pz, qx, qy, qz, qw; /* Twc translation + unit quaternion, world-from-camera */
+};
+
+vector<uint8_t> build_pose_packet(const pose &T, double timestamp, int cameraId, int trackingState)
+{
+    ssmp::packer pk;
+    pk.pack_map(6);
+    pk.pack("type");           pk.pack("pose");
+    pk.pack("timestamp");      pk.pack(timestamp);
+    pk.pack("camera_id");      pk.pack(cameraId);
+    pk.pack("tracking_state"); pk.pack(trackingState);
+    pk.pack("position");
+    pk.pack_map(3);
+    pk.pack("x"); pk.pack(T.px);
+    pk.pack("y"); pk.pack(T.py);
+    pk.pack("z"); pk.pack(T.pz);
+    pk.pack("orientation");
+    pk.pack_map(4);
+    pk.pack("x"); pk.pack(T.qx);
+    pk.pack("y"); pk.pack(T.qy);
+    pk.pack("z"); pk.pack(T.qz);
+    pk.pack("w"); pk.pack(T.qw);
+    return pk.buf;
+}
+
+bool write_all(int fd, const uint8_t *p, size_t n)
+{
+    while (n) {
+        const ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (k <= 0) return false;
+        p += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+
+bool send_framed(int fd, const vector<uint8_t> &payload)
+{
+    const uint32_t len = (uint32_t)payload.size();
+    const uint8_t header[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len};
+    return write_all(fd, header, 4) && write_all(fd, payload.data(), payload.size());
+}
+
+bool send_pose_packet(int fd, const pose &T, double timestamp, int cameraId, int trackingState)
+{
+    if (!send_framed(fd, build_pose_packet(T, timestamp, cameraId, trackingState))) {
+        cerr << "Failed to send pose packet: socket write failed" << endl;
+        return false;
+    }
+    return true;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && string(argv[1]) == "--selftest-pose") {
+        const pose T{0.25, -1.5, 3.0, 0.0, 0.7071067811865476, 0.0, 0.7071067811865476};
+        for (uint8_t b : build_pose_packet(T, 12.5, 1, TRACKING_OK)) printf("%02x", b);
+        printf("\n");
+        return 0;
+    }
+
+    const char *portEnv = getenv("ORB_SLAM3_WS_PORT");
+    if (portEnv == nullptr) {
+        cerr << "ORB_SLAM3_WS_PORT environment variable is not set." << endl;
+        return 1;
+    }
+    int port = 0;
+    try {
+        port = stoi(portEnv);
+    } catch (const exception &e) {
+        cerr << "Failed to parse ORB_SLAM3_WS_PORT: " << e.what() << endl;
+        return 1;
+    }
+    if (port <= 0 || port > 65535) {
+        cerr << "ORB_SLAM3_WS_PORT must be a valid TCP port (1-65535)." << endl;
+        return 1;
+    }
+
+    ss_orb_params params;
+    ss_orb_params_default(&params);
+    params.n_features = env_int("SENDSLAM_ORB_NFEATURES", params.n_features);
+    const int device = env_int("SENDSLAM_DEVICE", 0);
+    const bool emitFeatures = env_int("SENDSLAM_EMIT_FEATURES", 0) != 0;
+
+    ss_ctx *ctx = nullptr;
+    vector<float> vTimesTrack;
+    double previousTimestamp = -1.0;
+    vector<uint8_t> prevDesc;
+    int prevN = 0;
+
+    cout << endl << "-------" << endl;
+    cout << "Connecting to tcp://127.0.0.1:" << port << " ..." << endl;
+
+    int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+    sockaddr_in addr{};
+    addr.sin_family = AF_INET;
+    addr.sin_port = htons((uint16_t)port);
+    inet_pton(AF_INET, "127.0.0.1", &addr.sin_addr);
+    if (fd < 0 || ::connect(fd, (sockaddr *)&addr, sizeof(addr)) != 0) {
+        cerr << "TCP message processing failed: connect: " << strerror(errno) << endl;
+        return 1;
+    }
+    int one = 1;
+    setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+
+    /* returns 1 ok, 0 clean EOF before any byte, -1 error / EOF mid-message */
+    auto readExact = [fd](uint8_t *dst, size_t length) -> int {
+        size_t total = 0;
+        while (total < length) {
+            const ssize_t k = ::recv(fd, dst + total, length - total, 0);
+            if (k == 0) return total == 0 ? 0 : -1;
+            if (k < 0) {
+                if (errno == EINTR) continue;
+                return -1;
+            }
+            total += (size_t)k;
+        }
+        return 1;
+    };
+
+    constexpr size_t kMaxMessageSize = 50 * 1024 * 1024; /* 50 MB safety guard (:412) */
+    bool calibrationReceived = false;
+    int exitCode = 0;
+    vector<uint8_t> payload, pix;
+
+    cout << "Connection established. Awaiting calibration parameters..." << endl;
+
+    while (true) {
+        uint8_t lengthBuffer[4];
+        const int r = readExact(lengthBuffer, 4);
+        if (r == 0) {
+            cout << "Connection closed by server." << endl;
+            break;
+        }
+        if (r < 0) {
+            cerr << "TCP message processing failed: Unexpected EOF while reading from TCP socket" << endl;
+            exitCode = 1;
+            break;
+        }
+        const uint32_t messageLength = ((uint32_t)lengthBuffer[0] << 24) | ((uint32_t)lengthBuffer[1] << 16) |
+                                       ((uint32_t)lengthBuffer[2] << 8) | (uint32_t)lengthBuffer[3];
+        if (messageLength == 0) {
+            cerr << "Received empty MessagePack payload. Skipping." << endl;
+            continue;
+        }
+        if (messageLength > kMaxMessageSize) {
+            cerr << "Message exceeds safety limit (" << messageLength << " bytes)." << endl;
+            if (ctx) ss_destroy(ctx);
+            return 1;
+        }
+        payload.resize(messageLength);
+        if (readExact(payload.data(), payload.size()) != 1) {
+            cerr << "Connection closed before full message was received." << endl;
+            break;
+        }
+
+        MessagePacket packet;
+        ssmp::value root;
+        try {
+            root = ssmp::decoder(payload.data(), payload.size()).parse();
+            if (!parse_message(root, packet)) {
+                cerr << "Ignoring MessagePack payload without 'type' field." << endl;
+                continue;
+            }
+        } catch (const exception &ex) {
+            cerr << "Failed to parse MessagePack payload: " << ex.what() << endl;
+            continue;
+        }
+
+        if (packet.type == "terminate" || packet.type == "shutdown") {
+            cout << "Received termination request from server." << endl;
+            break;
+        }
+
+        if (packet.type == "calibration") {
+            if (!packet.camera_id) {
+                cerr << "Calibration message missing camera identifier." << endl;
+                continue;
+            }
+            if (!packet.hasCalibrationParameters) {
+                cerr << "Calibration message missing structured parameter payload." << endl;
+                continue;
+            }
+            /* a second calibration rebuilds the whole system (:491-518) */
+            if (ctx) {
+                ss_destroy(ctx);
+                ctx = nullptr;
+            }
+            const int rc = ss_create(device, &params, &ctx);
+            if (rc != SS_OK) {
+                /* the reference's System ctor would throw into the outer try (:636-650): exit 1.
+                 * No GPU means no service: there is no CPU path to fall back to. */
+                cerr << "TCP message processing failed: " << ss_last_error(nullptr) << endl;
+                ::close(fd);
+                return 1;
+            }
+            const CameraCalibration &c = packet.calibrationParameters;
+            ss_camera cam{};
+            snprintf(cam.type, sizeof(cam.type), "%s", c.type.c_str());
+            cam.fx = c.fx; cam.fy = c.fy; cam.cx = c.cx; cam.cy = c.cy;
+            cam.k1 = c.k1; cam.k2 = c.k2; cam.p1 = c.p1; cam.p2 = c.p2;
+            cam.width = c.width; cam.height = c.height; cam.fps = c.fps; cam.rgb = c.rgb;
+            cam.th_depth = c.stereoThDepth; cam.baseline = c.stereoBaseline; cam.depth_map_factor = c.depthMapFactor;
+            if (ss_set_calibration(ctx, packet.camera_id, &cam) != SS_OK) {
+                cerr << ss_last_error(ctx) << endl;
+                continue;
+            }
+            if (env_int("SENDSLAM_PRINT_SETTINGS", 0)) cout << settings_text(c, params);
+            calibrationReceived = true;
+            vTimesTrack.clear();
+            previousTimestamp = -1.0;
+            prevN = 0;
+            cout << "Calibration parameters received. SLAM system ready to process frames." << endl;
+            continue;
+        }
+
+        if (packet.type == "frame") {
+            if (!calibrationReceived) {
+                cerr << "Received frame before calibration. Ignoring." << endl;
+                continue;
+            }
+            if (!packet.camera_id) {
+                cerr << "Frame message missing camera identifier." << endl;
+                continue;
+            }
+            if (!packet.hasImage || packet.imageSize == 0) {
+                cerr << "Frame message missing binary image data." << endl;
+                continue;
+            }
+            if (!packet.hasTimestamp) {
+                cerr << "Frame message missing timestamp." << endl;
+                continue;
+            }
+            int w = 0, h = 0, ch = 0;
+            if (!decode_pnm(packet.imageData, packet.imageSize, w, h, ch, pix)) {
+                cerr << "Failed to decode frame image data." << endl;
+                continue;
+            }
+            if (!ctx) {
+                cerr << "SLAM system is not initialized. Skipping frame." << endl;
+                continue;
+            }
+
+            const auto t1 = chrono::steady_clock::now();
+            ss_frame_result res{};
+            int trackingState = NOT_INITIALIZED;
+            int nMatches = 0;
+            const int rc = ss_extract(ctx, packet.camera_id, pix.data(), w, h, ch, w * ch, packet.timestamp, &res);
+            if (rc != SS_OK) {
+                cerr << "Frame skipped: " << ss_last_error(ctx) << endl; /* bad frame => log + skip */
+                continue;
+            }
+            vector<uint8_t> curDesc(res.descriptors, res.descriptors + (size_t)res.n_keypoints * SS_DESC_BYTES);
+            if (prevN > 0 && res.n_keypoints > 0) {
+                vector<int32_t> idx((size_t)res.n_keypoints);
+                vector<uint16_t> d1((size_t)res.n_keypoints), d2((size_t)res.n_keypoints);
+                if (ss_match(ctx, curDesc.data(), res.n_keypoints, prevDesc.data(), prevN, 50, 9, 10, 0, idx.data(),
+                             d1.data(), d2.data()) == SS_OK)
+                    for (int32_t v : idx) nMatches += v >= 0;
+                else
+                    cerr << "Match skipped: " << ss_last_error(ctx) << endl;
+            }
+            prevDesc.swap(curDesc);
+            prevN = res.n_keypoints;
+            /* Pose estimation from the matches (two-view initialisation, PnP) is not built yet
+             * (DESIGN.md "next"): the state never reaches OK, so, like the reference while it is
+             * initialising, no pose packet is sent (:596). */
+            if (trackingState == TRACKING_OK) {
+                const pose T{0, 0, 0, 0, 0, 0, 1};
+                send_pose_packet(fd, T, packet.timestamp, packet.camera_id, trackingState);
+            }
+            if (emitFeatures) {
+                ssmp::packer pk;
+                pk.pack_map(6);
+                pk.pack("type");           pk.pack("features");
+                pk.pack("timestamp");      pk.pack(packet.timestamp);
+                pk.pack("camera_id");      pk.pack(packet.camera_id);
+                pk.pack("tracking_state"); pk.pack(trackingState);
+                pk.pack("n_keypoints");    pk.pack((int)res.n_keypoints);
+                pk.pack("n_matches");      pk.pack(nMatches);
+                send_framed(fd, pk.buf);
+            }
+            const auto t2 = chrono::steady_clock::now();
+            const double ttrack = chrono::duration_cast<chrono::duration<double>>(t2 - t1).count();
+            vTimesTrack.push_back((float)ttrack);
+
+            if (previousTimestamp > 0.0) { /* never outrun the timestamps (:618-624) */
+                const double interval = packet.timestamp - previousTimestamp;
+                if (ttrack < interval && !env_int("SENDSLAM_NO_PACING", 0)) usleep((useconds_t)((interval - ttrack) * 1e6));
+            }
+            previousTimestamp = packet.timestamp;
+            continue;
+        }
+
+        cerr << "Received MessagePack with unsupported type: '" << packet.type << "'." << endl;
+    }
+
+    ::shutdown(fd, SHUT_RDWR);
+    ::close(fd);
+
+    if (ctx) {
+        if (!vTimesTrack.empty()) {
+            sort(vTimesTrack.begin(), vTimesTrack.end());
+            const float totaltime = accumulate(vTimesTrack.begin(), vTimesTrack.end(), 0.0f);
+            cout << "-------" << endl;
+            cout << "Frames processed: " << vTimesTrack.size() << endl;
+            cout << "median tracking time: " << vTimesTrack[vTimesTrack.size() / 2] << endl;
+            cout << "mean tracking time: " << totaltime / vTimesTrack.size() << endl;
+        } else {
+            cout << "No frames processed." << endl;
+        }
+        ss_destroy(ctx);
+    }
+    return exitCode;
+}

@@ -1,0 +1,123 @@
+"""Multi-GPU shapes of the ORB path; one process per GPU over
+torch.distributed ("nccl" is RCCL over xGMI on ROCm; "gloo" for CPU rehearsal).
+
+Nothing in the reference corresponds to this (it has one camera, one backend process, one TCP
+link: README.md:5, application.ex:80); the three shapes come from BASELINE.json's configs:
+
+  config 3  independent cameras     shard_cameras(): camera ids per rank, NO collective
+  config 4  stereo, 2 GPUs          stereo_exchange(): all_gather of fixed-size descriptor
+                                    blocks (kp_capacity x 32 B per rank) + counts, then each
+                                    rank matches its own eye against the peer's
+  config 5  loop closure, N GPUs    loop_closure_query(): keyframe DB partitioned in contiguous
+                                    slabs; query broadcast; every rank reports raw
+                                    (d1, j1, d2) per query descriptor for its slab; all_gather
+                                    of N x nq x 8 B; element-wise fold in rank order (ties keep
+                                    the lower global index; second best = min over the losers'
+                                    d1 and everyone's d2); then the threshold / ratio test
+
+All messages are <= 64 KB per rank: latency-bound on xGMI, so one all_gather per exchange and
+no bucketing.  The fold is the same rule the match kernel uses across its train chunks
+(csrc/ss_kernels.hip merge_partial).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+NONE = 0xFFFF
+
+
+def shard_cameras(n_cameras: int, world: int, rank: int) -> List[int]:
+    """Camera ids (numbered from 1: camera_id 0 is rejected by the shim,
+    orbslam3_mono_networked.cc:479,528) handled by `rank`; round-robin, one per GPU first."""
+    return [c + 1 for c in range(n_cameras) if c % world == rank]
+
+
+def slab(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) slab of a database of n_items rows for `rank`."""
+    per = (n_items + world - 1) // world
+    b = min(rank * per, n_items)
+    return b, min(b + per, n_items)
+
+
+def _collective_device(t: torch.Tensor) -> torch.Tensor:
+    """gloo moves CPU tensors; nccl (RCCL) moves device tensors in place."""
+    return t.cpu() if dist.get_backend() == "gloo" else t
+
+
+def all_gather_fixed(t: torch.Tensor) -> List[torch.Tensor]:
+    world = dist.get_world_size()
+    src = _collective_device(t.contiguous())
+    out = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(out, src)
+    return [o.to(t.device) for o in out]
+
+
+def fold_partials(d1s: Sequence[torch.Tensor], j1s: Sequence[torch.Tensor], d2s: Sequence[torch.Tensor]):
+    """Element-wise merge of per-slab (d1, j1, d2), slabs in ascending global-index order."""
+    d1, j1, d2 = d1s[0].clone().long(), j1s[0].clone().long(), d2s[0].clone().long()
+    for e1, ej, e2 in zip(d1s[1:], j1s[1:], d2s[1:]):
+        e1, ej, e2 = e1.long(), ej.long(), e2.long()
+        better = e1 < d1
+        d2 = torch.where(better, torch.minimum(d1, e2), torch.minimum(d2, e1))
+        j1 = torch.where(better, ej, j1)
+        d1 = torch.where(better, e1, d1)
+    return d1, j1, d2
+
+
+def accept(d1: torch.Tensor, j1: torch.Tensor, d2: torch.Tensor, th: int = 50, ratio_num: int = 9,
+           ratio_den: int = 10) -> torch.Tensor:
+    ok = (j1 >= 0) & (d1 <= th) & (d1 * ratio_den < d2 * ratio_num)
+    return torch.where(ok, j1, torch.full_like(j1, -1))
+
+
+LocalMatch = Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]
+
+
+def hip_local_match(ctx) -> LocalMatch:
+    """Raw (th < 0) ss_match_device on this rank's GPU: (query u8[nq,32], train u8[nt,32]) device
+    tensors -> (j1 int32, d1, d2 as int32) device tensors."""
+    def run(q: torch.Tensor, t: torch.Tensor):
+        nq, nt = q.shape[0], t.shape[0]
+        idx = torch.empty(nq, dtype=torch.int32, device=q.device)
+        d1 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        d2 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        ctx.match_device(q.data_ptr(), nq, t.data_ptr() if nt else 0, nt, idx.data_ptr(), d1.data_ptr(),
+                         d2.data_ptr(), th=-1)
+        ctx.synchronize()
+        return idx, d1.to(torch.int32) & 0xFFFF, d2.to(torch.int32) & 0xFFFF
+    return run
+
+
+def loop_closure_query(query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, local_match: LocalMatch,
+                       th: int = 50, ratio_num: int = 9, ratio_den: int = 10, src: int = 0):
+    """Config 5.  `query` (u8 [nq,32]) is taken from rank `src` and broadcast; `db_slab` is this
+    rank's contiguous part of the keyframe-descriptor database, starting at global row
+    `slab_begin`.  Every rank returns the same (idx, d1, d2) over the WHOLE database."""
+    q = _collective_device(query.contiguous())
+    dist.broadcast(q, src=src)
+    q = q.to(query.device)
+    j1, d1, d2 = local_match(q, db_slab)
+    j1 = torch.where(j1 >= 0, j1.long() + slab_begin, j1.long())
+    part = torch.stack([d1.long(), j1, d2.long()])  # 3 x nq
+    parts = all_gather_fixed(part)
+    fd1, fj1, fd2 = fold_partials([p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts])
+    return accept(fd1, fj1, fd2, th, ratio_num, ratio_den).to(torch.int32), fd1, fd2
+
+
+def stereo_exchange(desc: torch.Tensor, n_kp: int, local_match: LocalMatch, th: int = 50, ratio_num: int = 9,
+                    ratio_den: int = 10):
+    """Config 4 (world size 2).  `desc` is this rank's fixed-size descriptor block
+    (u8 [kp_capacity, 32], rows >= n_kp unused).  Returns matches of this eye's keypoints
+    against the peer eye's: (idx into the peer's rows, d1, d2, peer_n_kp)."""
+    assert dist.get_world_size() == 2
+    rank = dist.get_rank()
+    blocks = all_gather_fixed(desc)
+    counts = all_gather_fixed(torch.tensor([n_kp], dtype=torch.int64, device=desc.device))
+    peer = 1 - rank
+    peer_n = int(counts[peer].item())
+    j1, d1, d2 = local_match(desc[:n_kp], blocks[peer][:peer_n])
+    idx = accept(d1.long(), j1.long(), d2.long(), th, ratio_num, ratio_den).to(torch.int32)
+    return idx, d1, d2, peer_n

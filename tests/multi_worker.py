@@ -1,0 +1,72 @@
+"""Worker entry points for the world_size-2 tests (spawned processes; test infrastructure)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "send-slam_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def oracle_local_match():
+    """CPU stand-in for the per-rank matcher in gloo rehearsals: the ORACLE in raw mode.  Test
+    infrastructure only: it checks the collective / fold logic, never the product kernel."""
+    import torch
+    from oracle import orb_oracle as O
+
+    def run(q, t):
+        idx, d1, d2 = O.match(q.cpu().numpy(), t.cpu().numpy().reshape(-1, 32), th=-1)
+        return (torch.from_numpy(idx.astype(np.int32)), torch.from_numpy(d1.astype(np.int32)),
+                torch.from_numpy(d2.astype(np.int32)))
+    return run
+
+
+def make_db(seed, n_db, nq):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    db = rng.integers(0, 256, size=(n_db, 32), dtype=np.uint8)
+    half = n_db // 2
+    db[3] = q[0]; db[half + 5] = q[0]          # exact duplicate in both slabs: lowest index wins, d2 = 0
+    db[half + 9] = q[1]                        # best lives in the second slab
+    db[7] = q[2]; db[7, 0] ^= 1                # distance-1 best in the first slab
+    db[half + 1] = q[2]; db[half + 1, 5] ^= 3  # distance-2 runner-up in the second slab
+    return q, db
+
+
+def run(rank, world, port, use_gpu, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from send_slam_amd import multi
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0") if use_gpu else torch.device("cpu")
+        if use_gpu:
+            from send_slam_amd import binding
+            ctx = binding.OrbContext(0)
+            local = multi.hip_local_match(ctx)
+        else:
+            local = oracle_local_match()
+        # config 5: loop closure over a partitioned database
+        q, db = make_db(5, 4001, 150)
+        b, e = multi.slab(len(db), world, rank)
+        query = torch.from_numpy(q if rank == 0 else np.zeros_like(q)).to(dev)
+        idx, d1, d2 = multi.loop_closure_query(query, torch.from_numpy(db[b:e]).to(dev), b, local, th=256, ratio_num=10)
+        np.savez(os.path.join(out_dir, f"lc_{rank}.npz"), idx=idx.cpu().numpy(), d1=d1.cpu().numpy(), d2=d2.cpu().numpy())
+        # config 4: stereo exchange of fixed-size descriptor blocks
+        rng = np.random.default_rng(100)
+        kcap = 192
+        eyes = [rng.integers(0, 256, size=(kcap, 32), dtype=np.uint8) for _ in range(2)]
+        counts = [150, 171]
+        eyes[1][:100] = eyes[0][:100]
+        eyes[1][:100, 4] ^= 0x0F  # the right eye sees the left eye's points 4 bits away
+        sidx, sd1, sd2, peer_n = multi.stereo_exchange(torch.from_numpy(eyes[rank]).to(dev), counts[rank], local)
+        np.savez(os.path.join(out_dir, f"st_{rank}.npz"), idx=sidx.cpu().numpy(), d1=sd1.cpu().numpy(), d2=sd2.cpu().numpy(),
+                 peer_n=peer_n)
+        if use_gpu:
+            ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,227 @@
+"""Drop-in boundary tests: wire-format golden bytes and the front-door binary against a fake
+host that plays SlamHandler's role (the counterpart of the reference's
+missing "fake backend").  CPU tests need no GPU; the end-to-end frame test is marked gpu.
+
+Reference: protocol produced at send_slam/lib/send_slam/slam_handler.ex:140-156,189-230,283-291,
+consumed at slam_backends/orb_slam_3/orbslam3_mono_networked.cc:284-339,423-630; pose packet
+:225-282 (157-byte payload, header 0000009d).
+"""
+import os
+import socket
+import struct
+import subprocess
+import threading
+
+import msgpack
+import numpy as np
+import pytest
+
+from send_slam_amd import backend, synth, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FRONTDOOR = backend.FRONTDOOR
+
+
+@pytest.fixture(scope="module")
+def frontdoor():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "send-slam_amd"), "-s"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "send-slam_amd", "frontdoor"), "-s"])
+    return FRONTDOOR
+
+
+def test_pose_packet_golden_bytes(frontdoor):
+    hexed = subprocess.check_output([frontdoor, "--selftest-pose"], text=True).strip()
+    got = bytes.fromhex(hexed)
+    want = wire.pose_packet(12.5, 1, 2, (0.25, -1.5, 3.0), (0.0, 0.7071067811865476, 0.0, 0.7071067811865476))
+    assert len(got) == 157 and want[:4] == bytes.fromhex("0000009d")  # SURVEY.md section 8(c) pin
+    assert got == want[4:]
+    pose = wire.handle_incoming_packet(got)
+    assert pose["type"] == "pose" and pose["camera_id"] == 1 and pose["tracking_state"] == 2
+    assert set(pose) == {"type", "timestamp", "camera_id", "tracking_state", "position", "orientation"}
+    assert pose["position"] == {"x": 0.25, "y": -1.5, "z": 3.0} and pose["orientation"]["w"] == 0.7071067811865476
+
+
+def test_host_packets_shape_and_framing():
+    dims = {"width": 640, "height": 480, "channels": 3}
+    k = [[500.0, 0, 320.0], [0, 510.0, 240.0], [0, 0, 1]]
+    pkt = wire.build_calibration_packet(k, [0.1, -0.2, 0.001, 0.002, 0.5], dims, camera_id=4, fps=30)
+    (n,) = struct.unpack(">I", pkt[:4])
+    assert n == len(pkt) - 4
+    m = msgpack.unpackb(pkt[4:], raw=False)
+    cam = m["calibration"]["camera"]
+    assert m["type"] == "calibration" and m["camera_id"] == 4
+    assert (cam["fx"], cam["fy"], cam["cx"], cam["cy"]) == (500.0, 510.0, 320.0, 240.0)
+    assert (cam["k1"], cam["k2"], cam["p1"], cam["p2"]) == (0.1, -0.2, 0.001, 0.002)
+    assert cam["rgb"] == 1 and cam["th_depth"] == 40.0 and cam["type"] == "PinHole" and len(cam) == 16
+    ppm = wire.encode_to_ppm(np.zeros((720, 1280, 3), np.uint8))
+    assert len(ppm) == 2764816  # 1280x720x3 PPM on the wire
+    fp = wire.build_frame_packet(ppm[:100], dims, camera_id=4, timestamp=1.5)
+    fm = msgpack.unpackb(fp[4:], raw=False)
+    assert fm["type"] == "frame" and isinstance(fm["frame"], bytes) and fm["encoding"] == "ppm"
+    pk, rest = wire.extract_packets(pkt + fp + fp[:7])
+    assert pk == [pkt[4:], fp[4:]] and rest == fp[:7]
+    assert wire.extract_packets(b"\x00\x00")[0] == []
+
+
+class FakeHost:
+    """Plays ThousandIsland + SlamHandler: listens, sends packets, collects what comes back."""
+
+    def __init__(self):
+        self.srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        self.srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self.srv.bind(("127.0.0.1", 0))
+        self.srv.listen(1)
+        self.port = self.srv.getsockname()[1]
+        self.conn = None
+        self.inbound = []
+        self._buf = b""
+
+    def accept(self, timeout=60):
+        self.srv.settimeout(timeout)
+        self.conn, _ = self.srv.accept()
+        self.conn.settimeout(timeout)
+
+    def send(self, data: bytes):
+        self.conn.sendall(data)
+
+    def recv_packets(self, n, timeout=60):
+        self.conn.settimeout(timeout)
+        while len(self.inbound) < n:
+            chunk = self.conn.recv(65536)
+            if not chunk:
+                break
+            pk, self._buf = wire.extract_packets(self._buf + chunk)
+            self.inbound.extend(msgpack.unpackb(p, raw=False) for p in pk)
+        return self.inbound
+
+    def close(self):
+        for s in (self.conn, self.srv):
+            try:
+                if s:
+                    s.close()
+            except OSError:
+                pass
+
+
+def run_backend(host, env=None):
+    e = {"SENDSLAM_NO_PACING": "1"}
+    e.update(env or {})
+    b = backend.HipBackend(port=host.port, env=e)
+    assert b.status() == {"state": "initial", "container_id": None, "last_seen": None}
+    tag, cid = b.start_container()
+    assert tag == "ok" and b.start_container() == ("ok", cid)  # idempotent like docker_handler.ex:82-84
+    return b
+
+
+def test_frontdoor_requires_port_env(frontdoor):
+    env = {k: v for k, v in os.environ.items() if k != "ORB_SLAM3_WS_PORT"}
+    r = subprocess.run([frontdoor], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "ORB_SLAM3_WS_PORT environment variable is not set." in r.stderr
+    r = subprocess.run([frontdoor], env=dict(env, ORB_SLAM3_WS_PORT="70000"), capture_output=True, text=True)
+    assert r.returncode == 1 and "must be a valid TCP port" in r.stderr
+
+
+def test_frontdoor_log_and_skip_policy_without_gpu_work(frontdoor):
+    """Everything the shim does before it needs the GPU: skip empty / malformed / typeless /
+    unknown messages, refuse frames before calibration, stop on "terminate"."""
+    host = FakeHost()
+    b = run_backend(host)
+    try:
+        host.accept()
+        host.send(struct.pack(">I", 0))                                   # empty payload -> skipped
+        host.send(struct.pack(">I", 3) + b"\xc1\xc1\xc1")                 # not MessagePack -> skipped
+        host.send(wire.encode_payload({"camera_id": 1}))                  # no 'type' -> ignored
+        host.send(wire.encode_payload({"type": "bogus"}))                 # unsupported type
+        host.send(wire.encode_payload({"type": "frame", "camera_id": 1, "timestamp": 0.0, "frame": b"P5"}))
+        host.send(wire.encode_payload({"type": "frame", "camera_id": 1, "timestamp": 0.0, "frame": "text"}))
+        host.send(wire.build_calibration_packet(np.eye(3), [0, 0, 0, 0], {"width": 8, "height": 8, "channels": 1}, camera_id=0))
+        host.send(wire.encode_payload({"type": "calibration", "camera_id": 1}))
+        host.send(wire.encode_payload({"type": "calibration", "camera_id": 1, "calibration": {"camera": {"fx": 1.0}}}))
+        host.send(wire.build_terminate_packet())
+        rc = b.wait(timeout=60)
+    finally:
+        host.close()
+    tag, text = b.logs(200)
+    assert tag == "ok" and rc == 0, text
+    for line in ["Received empty MessagePack payload. Skipping.", "Failed to parse MessagePack payload",
+                 "Ignoring MessagePack payload without 'type' field.",
+                 "Received MessagePack with unsupported type: 'bogus'.",
+                 "Received frame before calibration. Ignoring.",
+                 "Image data must be encoded as MessagePack bin",
+                 "Calibration message missing camera identifier.",
+                 "Calibration message missing structured parameter payload.",
+                 "Calibration section 'camera' is missing key 'type'",
+                 "Received termination request from server."]:
+        assert line in text, line
+    assert b.status()["state"] == "exited"
+
+
+def test_frontdoor_oversize_message_is_fatal(frontdoor):
+    host = FakeHost()
+    b = run_backend(host)
+    try:
+        host.accept()
+        host.send(struct.pack(">I", 50 * 1024 * 1024 + 1))
+        rc = b.wait(timeout=60)
+    finally:
+        host.close()
+    assert rc == 1 and "Message exceeds safety limit" in b.logs()[1]
+
+
+def test_frontdoor_without_gpu_fails_loudly_at_calibration(frontdoor):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    host = FakeHost()
+    b = run_backend(host)
+    try:
+        host.accept()
+        dims = {"width": 320, "height": 240, "channels": 1}
+        host.send(wire.build_calibration_packet(np.eye(3), [0, 0, 0, 0], dims))
+        rc = b.wait(timeout=60)
+    finally:
+        host.close()
+    assert rc == 1 and "no CPU path" in b.logs()[1]
+
+
+@pytest.mark.gpu
+def test_frontdoor_end_to_end_frames(frontdoor, oracle):
+    """Config 1 of BASELINE.json (plumbing): fake host <-> front door, calibration then frames;
+    every frame is extracted on the GPU; poses are sent only in state OK (none yet); the
+    optional 'features' message carries counts that equal the oracle's."""
+    w, h = 640, 480
+    frames = [synth.frame(40, w, h, t) for t in range(3)]
+    col = synth.color_frame(41, w, h)
+    host = FakeHost()
+    b = run_backend(host, {"SENDSLAM_EMIT_FEATURES": "1"})
+    try:
+        host.accept()
+        dims = {"width": w, "height": h, "channels": 1}
+        host.send(wire.build_calibration_packet([[500, 0, 320], [0, 500, 240], [0, 0, 1]], [0, 0, 0, 0], dims))
+        for t, f in enumerate(frames):
+            host.send(wire.build_frame_packet(wire.encode_to_ppm(f), dims, camera_id=1, timestamp=1.0 + t / 30))
+        host.send(wire.build_frame_packet(b"P6\n2 2\n255\n", dims, camera_id=1, timestamp=2.0))  # truncated -> skipped
+        host.send(wire.build_frame_packet(wire.encode_to_ppm(col), dict(dims, channels=3), camera_id=1, timestamp=2.1))
+        msgs = host.recv_packets(4)
+        host.send(wire.build_terminate_packet())
+        rc = b.wait(timeout=60)
+    finally:
+        host.close()
+    text = b.logs(200)[1]
+    assert rc == 0, text
+    assert "Failed to decode frame image data." in text and "Frames processed: 4" in text
+    assert "median tracking time:" in text and "mean tracking time:" in text
+    assert [m["type"] for m in msgs] == ["features"] * 4 and all(wire.handle_incoming_packet(msgpack.packb(m)) is None for m in msgs)
+    p = oracle.default_params()
+    prev = None
+    for m, f in zip(msgs[:3], frames):
+        kps, desc, _ = oracle.extract(f, p)
+        assert m["n_keypoints"] == len(kps) and m["camera_id"] == 1
+        if prev is not None:
+            idx, _, _ = oracle.match(desc, prev)
+            assert m["n_matches"] == int((idx >= 0).sum())
+        prev = desc
+    # colour frame: PPM is R,G,B on the wire, a BGR Mat after decode, weighed with rgb: 1
+    gray = oracle.gray(np.ascontiguousarray(col), 1)
+    kps, desc, _ = oracle.extract(gray, p)
+    assert msgs[3]["n_keypoints"] == len(kps)
