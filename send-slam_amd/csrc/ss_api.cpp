@@ -56,9 +56,11 @@ struct ss_ctx {
     ss_rtab *d_rtab = nullptr;
     uint32_t *d_tiles = nullptr;
 
-    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr;
-    int32_t *cell_cnt = nullptr;
+    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *flags = nullptr;
+    uint32_t *cell_cnt = nullptr;
+    uint16_t *d_cinfo = nullptr;
     uint32_t *cand = nullptr, *qbuf0 = nullptr, *qbuf1 = nullptr;
+    uint16_t *corner_list = nullptr, *corner_cnt = nullptr; /* per tile: FAST corners (score > 0) */
     ss_qnode *nodes = nullptr;
     int32_t *lists = nullptr;
     uint32_t *sel = nullptr;
@@ -167,10 +169,14 @@ void free_geometry_buffers(ss_ctx *c)
     dev_free(c->pyr);
     dev_free(c->blur);
     dev_free(c->score);
+    dev_free(c->flags);
+    dev_free(c->d_cinfo);
     dev_free(c->cell_cnt);
     dev_free(c->cand);
     dev_free(c->qbuf0);
     dev_free(c->qbuf1);
+    dev_free(c->corner_list);
+    dev_free(c->corner_cnt);
     dev_free(c->nodes);
     dev_free(c->lists);
     dev_free(c->sel);
@@ -208,10 +214,15 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->score, B * g.block_bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->cell_cnt, B * g.n_cells * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->flags, B * g.block_bytes));
+    HIP_TRY(c, hipMalloc((void **)&c->d_cinfo, c->tabs.cinfo.size() * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(c->d_cinfo, c->tabs.cinfo.data(), c->tabs.cinfo.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->cell_cnt, B * g.n_cells * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->cand, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf0, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf1, B * g.cand_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->corner_list, B * g.tiles_total * (size_t)(SS_TILE_W * SS_TILE_H) * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->corner_cnt, B * g.tiles_total * sizeof(uint16_t)));
     HIP_TRY(c, hipMalloc((void **)&c->nodes, B * g.node_total * sizeof(ss_qnode)));
     HIP_TRY(c, hipMalloc((void **)&c->lists, B * g.item_total * 2 * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->sel, B * g.sel_total * sizeof(uint32_t)));
@@ -258,19 +269,20 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     {
         stage_timer t(c, "fast_score", n * all_px);
-        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles, n);
+        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles, c->corner_list, c->corner_cnt, n);
     }
     {
         stage_timer t(c, "blur", n * 2 * all_px);
         ssk_blur(s, c->pyr, c->blur, c->dg, g, c->d_tiles, n);
     }
+    HIP_TRY(c, hipMemsetAsync(c->cell_cnt, 0, (size_t)n * g.n_cells * sizeof(uint32_t), s));
     {
-        stage_timer t(c, "cells_count", n * all_px);
-        ssk_cells(s, false, c->score, c->dg, g, c->cell_cnt, c->cand, c->state, n);
+        stage_timer t(c, "nms", 0);
+        ssk_nms(s, c->score, c->flags, c->dg, g, c->d_tiles, c->corner_list, c->corner_cnt, c->d_cinfo, c->cell_cnt, n);
     }
     {
         stage_timer t(c, "cells_emit", n * all_px);
-        ssk_cells(s, true, c->score, c->dg, g, c->cell_cnt, c->cand, c->state, n);
+        ssk_cells_emit(s, c->score, c->flags, c->dg, g, c->cell_cnt, c->cand, c->state, n);
     }
     {
         stage_timer t(c, "quadtree", 0);

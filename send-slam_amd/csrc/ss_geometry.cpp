@@ -126,6 +126,7 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
 
     tabs->rtab.clear();
     tabs->tiles.clear();
+    tabs->cinfo.clear();
     uint32_t off = 0;
     int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile_base = 0;
     for (int l = 0; l < p.n_levels; l++) {
@@ -153,6 +154,30 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
         L.h_cell = (int)ceilf(fh / L.n_rows);
         L.cell_base = cell_base;
         cell_base += L.n_cols * L.n_rows;
+
+        /* per-column / per-row window info: cell c evaluates [ini+3, max-3) where
+         * max = min(ini + cell + 6, maxBorder); cells starting at or past maxBorder - 6 (columns)
+         * / - 3 (rows) are skipped (ComputeKeyPointsOctTree's two `continue`s) */
+        for (int axis = 0; axis < 2; axis++) {
+            const int n = axis == 0 ? L.w : L.h;
+            const int n_cells = axis == 0 ? L.n_cols : L.n_rows;
+            const int cell = axis == 0 ? L.w_cell : L.h_cell;
+            const int max_b = axis == 0 ? max_bx : max_by;
+            const int skip_from = axis == 0 ? max_bx - 6 : max_by - 3;
+            const size_t base = tabs->cinfo.size();
+            (axis == 0 ? L.xinfo_off : L.yinfo_off) = (int)base;
+            tabs->cinfo.resize(base + (size_t)align_up(n, 4), 0);
+            for (int k = 0; k < n_cells; k++) {
+                const int ini = min_b + k * cell;
+                if (ini >= skip_from) continue;
+                int mx = ini + cell + 6;
+                if (mx > max_b) mx = max_b;
+                const int lo = ini + 3, hi = mx - 3; /* [lo, hi) */
+                for (int p = lo; p < hi; p++)
+                    tabs->cinfo[base + p] = (uint16_t)(SS_CI_VALID | (p == lo ? SS_CI_LOW : 0) |
+                                                       (p == hi - 1 ? SS_CI_HIGH : 0) | (uint16_t)k);
+            }
+        }
 
         /* quadtree roots: nIni = round(width / height), hX = width / nIni */
         L.n_ini = (int)roundf((float)(max_bx - min_b) / (float)(max_by - min_b));

@@ -11,6 +11,7 @@
 struct ss_host_tables {
     std::vector<ss_rtab> rtab;   /* resize coefficient tables, all levels */
     std::vector<uint32_t> tiles; /* level << 20 | tile_y << 8 | tile_x, all levels */
+    std::vector<uint16_t> cinfo; /* cell-window info per column / row, all levels */
 };
 
 int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,

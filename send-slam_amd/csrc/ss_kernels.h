@@ -13,11 +13,14 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
                 int level, int n_frames);
 void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *tiles, int n_frames);
+                    const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames);
 void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
               const uint32_t *tiles, int n_frames);
-void ssk_cells(hipStream_t s, bool emit, const uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-               int32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames);
+void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
+             const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
+             uint32_t *cell_cnt, int n_frames);
+void ssk_cells_emit(hipStream_t s, const uint8_t *score, const uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
+                    const uint32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames);
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
                   uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state,
                   int n_frames);

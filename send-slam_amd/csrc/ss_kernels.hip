@@ -7,8 +7,9 @@
  *   K0  k_ingest        cvtColor RGB/BGR -> gray (or pitched copy) into pyramid level 0
  *   K1  k_resize        ORBextractor::ComputePyramid: cv::resize INTER_LINEAR, level by level
  *   K2  k_fast_score    cv::FAST-9-16 corner response R-1 for every pixel (threshold-free)
- *   K3  k_cells<EMIT>   35-px cell grid: NMS inside the cell, iniTh -> minTh fallback,
- *                       ordered compaction into the candidate list
+ *   K3  k_nms, k_cells_emit   35-px cell grid: NMS inside each cell window (sparse, on the corner
+ *                       list FAST leaves; atomics for per-cell counts), iniTh -> minTh fallback, ordered
+ *                       compaction into the candidate list (one wave per cell)
  *   K4  k_quadtree      ORBextractor::DistributeOctTree, one wave per (frame, level)
  *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
@@ -125,9 +126,15 @@ __device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k com
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr,
                                                     uint8_t *__restrict__ score,
                                                     const ss_geom *__restrict__ g,
-                                                    const uint32_t *__restrict__ tiles)
+                                                    const uint32_t *__restrict__ tiles,
+                                                    uint16_t *__restrict__ corner_list,
+                                                    uint16_t *__restrict__ corner_cnt)
 {
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
+    __shared__ uint32_t out_tile[SS_TILE_H][SS_TILE_W / 4];
+    __shared__ uint16_t list[SS_TILE_W * SS_TILE_H];
+    __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H];
+    __shared__ int n_list, n_corner;
     const uint32_t t = tiles[blockIdx.x];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
     const ss_level &L = g->lv[level];
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     const uint8_t *img = pyr + fb;
     const int w = L.w, h = L.h, pitch = L.pitch;
 
+    if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     for (int idx = threadIdx.x; idx < FT_ROWS * FT_WORDS; idx += 256) {
         const int r = idx / FT_WORDS, c = idx - r * FT_WORDS;
         const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
@@ -144,24 +152,45 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     }
     __syncthreads();
 
+    /* Phase 1, every pixel: the compass test.  Any 9 contiguous ring pixels contain >= 2 of the
+     * 4 compass points (ring 0, 4, 8, 12), so a corner at threshold t needs >= 2 compass points
+     * darker than v - t or >= 2 brighter than v + t.  Only a few % of the pixels pass; they are
+     * queued in LDS and scored in phase 2, the rest get 0 without the 100-op arc search. */
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    uint32_t rw[7][3];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) rw[r][c] = lds[ty + r][tx + c];
-    }
-    constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     const int min_th = g->min_th;
     const int y = y0 + ty;
-    uint32_t out = 0;
+    {
+        const uint32_t up[3] = {lds[ty][tx], lds[ty][tx + 1], lds[ty][tx + 2]};
+        const uint32_t mid[3] = {lds[ty + 3][tx], lds[ty + 3][tx + 1], lds[ty + 3][tx + 2]};
+        const uint32_t dn[3] = {lds[ty + 6][tx], lds[ty + 6][tx + 1], lds[ty + 6][tx + 2]};
+        out_tile[ty][tx] = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int v = tile_byte(rw[3], 4 + i);
+        for (int i = 0; i < 4; i++) {
+            const int v = tile_byte(mid, 4 + i);
+            const int d0 = v - tile_byte(dn, 4 + i), d8 = v - tile_byte(up, 4 + i);
+            const int d4 = v - tile_byte(mid, 7 + i), d12 = v - tile_byte(mid, 1 + i);
+            const int n_dark = (d0 > min_th) + (d4 > min_th) + (d8 > min_th) + (d12 > min_th);
+            const int n_bright = (d0 < -min_th) + (d4 < -min_th) + (d8 < -min_th) + (d12 < -min_th);
+            const int x = x0 + 4 * tx + i;
+            const bool inside = x >= 3 && x < w - 3 && y >= 3 && y < h - 3;
+            if (inside && (n_dark >= 2 || n_bright >= 2)) list[atomicAdd(&n_list, 1)] = (uint16_t)((ty << 8) | (4 * tx + i));
+        }
+    }
+    __syncthreads();
+
+    /* Phase 2, queued pixels only: R = max over the 16 arcs of min9(v - p) and of min9(p - v) */
+    constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    const uint8_t *tile8 = (const uint8_t *)&lds[0][0];
+    uint8_t *out8 = (uint8_t *)&out_tile[0][0];
+    const int n = n_list;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int ly = list[e] >> 8, lx = list[e] & 0xFF;
+        const uint8_t *c = tile8 + (ly + 3) * (FT_WORDS * 4) + 4 + lx;
+        const int v = c[0];
         int d[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - tile_byte(rw[3 + RDY[k]], 4 + i + RDX[k]);
+        for (int k = 0; k < 16; k++) d[k] = v - c[RDY[k] * (FT_WORDS * 4) + RDX[k]];
         int lo3[16], hi3[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -170,17 +199,28 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         }
         int dark = -256, bright = 256; /* max over arcs of min(d); min over arcs of max(d) */
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            dark = imax(dark, min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-            bright = imin(bright, max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        for (int k = 0; k < 16; k += 2) {
+            dark = max3(dark, min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]),
+                        min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
+            bright = min3(bright, max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]),
+                          max3(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]));
         }
         const int R = imax(dark, -bright);
-        const int x = x0 + 4 * tx + i;
-        const bool inside = x >= 3 && x < w - 3 && y >= 3 && y < h - 3;
-        const uint32_t s = (inside && R > min_th) ? (uint32_t)(R - 1) : 0u;
-        out |= s << (8 * i);
+        if (R > min_th) {
+            out8[ly * SS_TILE_W + lx] = (uint8_t)(R - 1);
+            corners[atomicAdd(&n_corner, 1)] = list[e];
+        }
     }
-    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+    __syncthreads();
+    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ty][tx];
+    /* corners (score > 0) go to this tile's slot of the corner list, any order: the sparse NMS
+     * pass works on these lists instead of sweeping the whole map.  A slot holds a full tile,
+     * so nothing can overflow and no global atomic is needed. */
+    const size_t slot = (size_t)blockIdx.y * g->tiles_total + blockIdx.x;
+    const int nc = n_corner;
+    uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H);
+    for (int e = threadIdx.x; e < nc; e += 256) cl[e] = corners[e];
+    if (threadIdx.x == 0) corner_cnt[slot] = (uint16_t)nc;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -259,22 +299,75 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* K3: one wave per grid cell.  The cell's evaluated window of the score map (plus a zero  */
-/* 1-px frame: FAST_t's ring buffers hold 0 outside the evaluated window) is staged in LDS;*/
-/* NMS = strictly greater than all 8 neighbours at the cell's threshold; if no keypoint    */
-/* survives at iniTh the cell is redone at minTh.  COUNT pass: survivors per cell.  EMIT   */
-/* pass: ordered compaction (cells row-major, pixels row-major inside a cell = upstream's  */
-/* push_back order) via ballot + prefix.                                                   */
+/* K3a: non-maximum suppression inside the FAST cell windows, on the SPARSE corner list the  */
+/* FAST kernel left (a few % of the pixels).  cv::FAST runs per cell sub-image, so a pixel      */
+/* competes only with neighbours of ITS window (FAST_t's ring buffers hold 0 outside it); the  */
+/* per-column / per-row tables say whether a pixel is evaluated at all and whether it is the   */
+/* first / last of its window.  Output: a flag byte per corner pixel (bit 0 keep at iniTh,     */
+/* bit 1 keep at minTh; bytes where score == 0 are never written nor read) and, through sparse */
+/* atomics, the two survivor counts of every cell (low / high half of one word).               */
 /* ------------------------------------------------------------------------------------ */
-#define CELL_PITCH 72
-#define CELL_ROWS 72
-
-template <bool EMIT>
-__global__ __launch_bounds__(64) void k_cells(const uint8_t *__restrict__ score,
-                                              const ss_geom *__restrict__ g, int32_t *__restrict__ cell_cnt,
-                                              uint32_t *__restrict__ cand, ss_level_state *__restrict__ state)
+__global__ __launch_bounds__(64) void k_nms(const uint8_t *__restrict__ score, uint8_t *__restrict__ flags,
+                                            const ss_geom *__restrict__ g, const uint32_t *__restrict__ tiles,
+                                            const uint16_t *__restrict__ corner_list, const uint16_t *__restrict__ corner_cnt,
+                                            const uint16_t *__restrict__ cinfo, uint32_t *__restrict__ cell_cnt)
 {
-    __shared__ uint8_t tile[CELL_ROWS][CELL_PITCH];
+    const int frame = blockIdx.y;
+    const size_t slot = (size_t)frame * g->tiles_total + blockIdx.x;
+    const int n = corner_cnt[slot];
+    if (n == 0) return;
+    const uint32_t t = tiles[blockIdx.x];
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const ss_level &L = g->lv[level];
+    const size_t fb = (size_t)frame * g->block_bytes + L.off;
+    const uint8_t *sm = score + fb;
+    const uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H);
+    const int pitch = L.pitch, ini_th = g->ini_th;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        const uint32_t rec = cl[i];
+        const int x = x0 + (int)(rec & 0xFF), y = y0 + (int)(rec >> 8);
+        const uint32_t xi = cinfo[L.xinfo_off + x], yi = cinfo[L.yinfo_off + y];
+        uint8_t out = 0;
+        if ((xi & SS_CI_VALID) && (yi & SS_CI_VALID)) {
+            const uint8_t *c = sm + (size_t)y * pitch + x;
+            const int s = c[0];
+            const bool left_ok = !(xi & SS_CI_LOW), right_ok = !(xi & SS_CI_HIGH);
+            const bool up_ok = !(yi & SS_CI_LOW), down_ok = !(yi & SS_CI_HIGH);
+            int m = 0, m_ini = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const bool ok = (dx < 0 ? left_ok : dx > 0 ? right_ok : true) &&
+                                    (dy < 0 ? up_ok : dy > 0 ? down_ok : true);
+                    const int nb = ok ? (int)c[dy * pitch + dx] : 0;
+                    m = imax(m, nb);
+                    m_ini = imax(m_ini, nb >= ini_th ? nb : 0);
+                }
+            const bool k_min = s > m, k_ini = s >= ini_th && s > m_ini;
+            out = (uint8_t)((k_ini ? 1 : 0) | (k_min ? 2 : 0));
+            if (out) {
+                const int cell = L.cell_base + (int)(yi & SS_CI_CELL) * L.n_cols + (int)(xi & SS_CI_CELL);
+                atomicAdd(cell_cnt + (size_t)frame * g->n_cells + cell, (k_min ? 1u : 0u) | (k_ini ? 0x10000u : 0u));
+            }
+        }
+        flags[fb + (size_t)y * pitch + x] = out; /* defined exactly where score != 0 */
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K3b: ordered compaction, one wave per cell.  A cell that kept anything at iniTh uses its */
+/* iniTh survivors, otherwise its minTh survivors (the FAST(...,minThFAST) retry).  Output    */
+/* order = upstream's push_back order: cells row-major, pixels row-major inside a cell.  The  */
+/* window is read as aligned dwords of the flag map, several rows per wave instruction.       */
+/* ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int cell_count_of(uint32_t c) { return (c >> 16) ? (int)(c >> 16) : (int)(c & 0xFFFFu); }
+
+__global__ __launch_bounds__(64) void k_cells_emit(const uint8_t *__restrict__ score, const uint8_t *__restrict__ flags,
+                                                   const ss_geom *__restrict__ g, const uint32_t *__restrict__ cell_cnt,
+                                                   uint32_t *__restrict__ cand, ss_level_state *__restrict__ state)
+{
     const int frame = blockIdx.y, cell = blockIdx.x;
     int level = 0;
     for (int l = 1; l < g->n_levels; l++)
@@ -283,73 +376,14 @@ __global__ __launch_bounds__(64) void k_cells(const uint8_t *__restrict__ score,
     const int loc = cell - L.cell_base;
     const int ci = loc / L.n_cols, cj = loc - ci * L.n_cols;
     const int lane = lane_id();
-    int32_t *cnt = cell_cnt + (size_t)frame * g->n_cells;
+    const uint32_t *cnt = cell_cnt + (size_t)frame * g->n_cells;
     const bool last_cell = loc == L.n_cols * L.n_rows - 1;
 
-    const int max_bx = L.w - SS_EDGE_THRESHOLD + 3, max_by = L.h - SS_EDGE_THRESHOLD + 3;
-    const int ini_y = SS_MIN_BORDER + ci * L.h_cell, ini_x = SS_MIN_BORDER + cj * L.w_cell;
-    const int max_y = imin(ini_y + L.h_cell + 6, max_by), max_x = imin(ini_x + L.w_cell + 6, max_bx);
-    const bool skipped = ini_y >= max_by - 3 || ini_x >= max_bx - 6;
-    const int ex0 = ini_x + 3, ey0 = ini_y + 3;
-    const int ew = skipped ? 0 : imax(max_x - 3 - ex0, 0), eh = skipped ? 0 : imax(max_y - 3 - ey0, 0);
-
-    int count = 0;
-    bool use_ini = false;
-    if (ew > 0 && eh > 0) {
-        const uint8_t *sm = score + (size_t)frame * g->block_bytes + L.off;
-        for (int r = 0; r < eh + 2; r++) {
-            for (int c = lane; c < ew + 2; c += WAVE) {
-                uint8_t v = 0;
-                if (r >= 1 && r <= eh && c >= 1 && c <= ew)
-                    v = sm[(size_t)(ey0 - 1 + r) * L.pitch + (ex0 - 1 + c)];
-                tile[r][c] = v;
-            }
-        }
-        __syncthreads();
-        const int ini_th = g->ini_th;
-        int n_ini = 0, n_min = 0;
-        if (!EMIT) {
-            for (int r = 1; r <= eh; r++) {
-                for (int cb = 1; cb <= ew; cb += WAVE) {
-                    const int c = cb + lane;
-                    bool k_ini = false, k_min = false;
-                    if (c <= ew) {
-                        const int s = tile[r][c];
-                        if (s > 0) {
-                            int m = 0, m_ini = 0;
-#pragma unroll
-                            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                                for (int dx = -1; dx <= 1; dx++) {
-                                    if (dx == 0 && dy == 0) continue;
-                                    const int n = tile[r + dy][c + dx];
-                                    m = imax(m, n);
-                                    m_ini = imax(m_ini, n >= ini_th ? n : 0);
-                                }
-                            k_min = s > m;
-                            k_ini = s >= ini_th && s > m_ini;
-                        }
-                    }
-                    n_ini += __popcll(__ballot(k_ini));
-                    n_min += __popcll(__ballot(k_min));
-                }
-            }
-            use_ini = n_ini > 0;
-            count = use_ini ? n_ini : n_min;
-        } else {
-            const int stored = cnt[cell];
-            use_ini = (stored >> 30) & 1;
-            count = stored & 0x3FFFFFFF;
-        }
-    }
-    if (!EMIT) {
-        if (lane == 0) cnt[cell] = count | (use_ini ? (1 << 30) : 0);
-        return;
-    }
-
-    /* EMIT: offset = survivors of all earlier cells of this level */
+    const uint32_t mine = cnt[cell];
+    const int count = cell_count_of(mine);
+    const bool use_ini = (mine >> 16) != 0;
     int before = 0;
-    for (int c = L.cell_base + lane; c < cell; c += WAVE) before += cnt[c] & 0x3FFFFFFF;
+    for (int c = L.cell_base + lane; c < cell; c += WAVE) before += cell_count_of(cnt[c]);
     before = wave_sum(before);
     ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
     if (before + count > L.cand_cap) {
@@ -358,36 +392,50 @@ __global__ __launch_bounds__(64) void k_cells(const uint8_t *__restrict__ score,
     }
     if (last_cell && lane == 0) st->n_cand = before + count;
     if (count == 0) return;
+
+    const int max_bx = L.w - SS_EDGE_THRESHOLD + 3, max_by = L.h - SS_EDGE_THRESHOLD + 3;
+    const int ini_y = SS_MIN_BORDER + ci * L.h_cell, ini_x = SS_MIN_BORDER + cj * L.w_cell;
+    const int ex0 = ini_x + 3, ex1 = imin(ini_x + L.w_cell + 6, max_bx) - 3;
+    const int ey0 = ini_y + 3, ey1 = imin(ini_y + L.h_cell + 6, max_by) - 3;
+    const int g0 = ex0 >> 2, n_groups = ((ex1 - 1) >> 2) - g0 + 1; /* aligned dwords covering [ex0, ex1) */
+    const int rows_per_it = WAVE / n_groups;
+    const int r = lane / n_groups, gi = lane - r * n_groups;
+    const size_t fb = (size_t)frame * g->block_bytes + L.off;
+    const uint32_t bit = use_ini ? 0x01010101u : 0x02020202u;
     uint32_t *out = cand + (size_t)frame * g->cand_total + L.cand_base;
-    const int ini_th = g->ini_th;
     int pos = before;
-    for (int r = 1; r <= eh; r++) {
-        for (int cb = 1; cb <= ew; cb += WAVE) {
-            const int c = cb + lane;
-            bool keep = false;
-            int s = 0;
-            if (c <= ew) {
-                s = tile[r][c];
-                if (s > 0 && (!use_ini || s >= ini_th)) {
-                    int m = 0;
+    for (int yb = ey0; yb < ey1; yb += rows_per_it) {
+        const int y = yb + r;
+        const int xw = 4 * (g0 + gi);
+        uint32_t keep = 0, sc = 0;
+        if (r < rows_per_it && y < ey1) {
+            sc = *(const uint32_t *)(score + fb + (size_t)y * L.pitch + xw);
+            /* bytes outside [ex0, ex1) belong to the neighbouring cells */
 #pragma unroll
-                    for (int dy = -1; dy <= 1; dy++)
+            for (int b = 0; b < 4; b++)
+                if (xw + b < ex0 || xw + b >= ex1) sc &= ~(0xFFu << (8 * b));
+            if (sc) {
+                keep = *(const uint32_t *)(flags + fb + (size_t)y * L.pitch + xw) & bit;
 #pragma unroll
-                        for (int dx = -1; dx <= 1; dx++) {
-                            if (dx == 0 && dy == 0) continue;
-                            const int n = tile[r + dy][c + dx];
-                            m = imax(m, (!use_ini || n >= ini_th) ? n : 0);
-                        }
-                    keep = s > m;
-                }
+                for (int b = 0; b < 4; b++)
+                    if (!(sc & (0xFFu << (8 * b)))) keep &= ~(0xFFu << (8 * b)); /* flag bytes exist only under corners */
             }
-            const uint64_t mask = __ballot(keep);
-            if (keep) {
-                const int x = ex0 - 1 + c, y = ey0 - 1 + r; /* level coordinates */
-                out[pos + __popcll(mask & lanemask_lt())] = SS_PACK(x - SS_MIN_BORDER, y - SS_MIN_BORDER, s);
-            }
-            pos += __popcll(mask);
         }
+        const int c = __popc(keep);
+        int incl = c; /* inclusive prefix over lanes = row-major order */
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const int v = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += v;
+        }
+        if (c) {
+            int p = pos + incl - c;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (keep & (0xFFu << (8 * b)))
+                    out[p++] = SS_PACK(xw + b - SS_MIN_BORDER, y - SS_MIN_BORDER, (sc >> (8 * b)) & 0xFFu);
+        }
+        pos += __shfl(incl, WAVE - 1, WAVE);
     }
 }
 
@@ -1087,9 +1135,9 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
 }
 
 void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *tiles, int n_frames)
+                    const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles);
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt);
 }
 
 void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
@@ -1098,13 +1146,18 @@ void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *d
     hipLaunchKernelGGL(k_blur, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, blur, dg, tiles);
 }
 
-void ssk_cells(hipStream_t s, bool emit, const uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-               int32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames)
+void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
+             const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
+             uint32_t *cell_cnt, int n_frames)
 {
-    if (emit)
-        hipLaunchKernelGGL(k_cells<true>, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, dg, cell_cnt, cand, state);
-    else
-        hipLaunchKernelGGL(k_cells<false>, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, dg, cell_cnt, cand, state);
+    hipLaunchKernelGGL(k_nms, dim3(hg.tiles_total, n_frames), dim3(64), 0, s, score, flags, dg, tiles, corner_list, corner_cnt,
+                       cinfo, cell_cnt);
+}
+
+void ssk_cells_emit(hipStream_t s, const uint8_t *score, const uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
+                    const uint32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames)
+{
+    hipLaunchKernelGGL(k_cells_emit, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, flags, dg, cell_cnt, cand, state);
 }
 
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,

@@ -46,6 +46,8 @@ typedef struct {
     int32_t tile_base, tiles_x, tiles_y;
     /* resize tables for building THIS level from level-1 (entries of 8 bytes) */
     int32_t xtab_off, ytab_off;
+    /* cell-window tables (u16 per column / row of the level): SS_CI_* bits | cell index */
+    int32_t xinfo_off, yinfo_off;
     /* quadtree roots */
     int32_t n_ini;
     float hx;
@@ -70,6 +72,13 @@ typedef struct {
     int32_t umax[16];
     ss_level lv[SS_MAX_LEVELS_];
 } ss_geom;
+
+/* cell-window info of one column (or row): is it inside an evaluated FAST window, is it the
+ * first / last pixel of that window (no NMS neighbour on that side), which cell */
+#define SS_CI_VALID 0x2000u
+#define SS_CI_LOW 0x4000u
+#define SS_CI_HIGH 0x8000u
+#define SS_CI_CELL 0x03FFu
 
 /* resize table entries */
 typedef struct {
