@@ -584,20 +584,38 @@ __device__ void std_sort_items(uint64_t *a, int n)
         sort_insertion(a, 0, n);
 }
 
+/* One wave per tree: lanes hand data to each other through memory, but a wave's memory
+ * instructions are issued and serviced in program order (LLVM AMDGPU memory model: wavefront
+ * scope needs no cache action or wait), so only the COMPILER must be kept from moving accesses.
+ * No s_waitcnt vmcnt(0), no s_barrier: a dependent load simply waits for its own data. */
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#define QT_LDS_NODES 1024 /* first nodes of a tree live in LDS, later ones in the global table */
+
 struct qt_ctx {
     uint32_t *buf[2];
-    ss_qnode *nodes;
+    ss_qnode *nodes;      /* global table */
+    ss_qnode *lds_nodes;  /* LDS cache for indices < QT_LDS_NODES */
     int node_cap;
     int n_nodes;
     int size; /* lNodes.size() */
     int error;
 };
 
+__device__ __forceinline__ ss_qnode *qt_node(const qt_ctx &q, int idx)
+{
+    return idx < QT_LDS_NODES ? q.lds_nodes + idx : q.nodes + idx;
+}
+
 /* ExtractorNode::DivideNode on node idx.  Returns the number of children made; their node
  * indices are n_nodes_before .. n_nodes_before + made - 1 in n1..n4 order. */
 __device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by creation order */)
 {
-    const ss_qnode nd = q.nodes[idx];
+    const ss_qnode nd = *qt_node(q, idx);
     const int x0 = rfl(nd.x0), x1 = rfl(nd.x1), y0 = rfl(nd.y0), y1 = rfl(nd.y1);
     const int beg = rfl(nd.beg), cnt = rfl(nd.cnt), b = (rfl(nd.flags) >> 2) & 1;
     const int xm = x0 + ((x1 - x0 + 1) >> 1); /* ceil((float)(UR.x-UL.x)/2) */
@@ -647,7 +665,7 @@ __device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by crea
             run[k] += __popcll(m);
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if (q.n_nodes + 4 > q.node_cap) {
         q.error = -5;
@@ -667,16 +685,16 @@ __device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by crea
             ch.beg = beg + o[k];
             ch.cnt = c[k];
             ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((b ^ 1) << 2);
-            if (lane == 0) q.nodes[q.n_nodes] = ch;
+            if (lane == 0) *qt_node(q, q.n_nodes) = ch;
             child_cnt[made] = c[k];
             q.n_nodes++;
             q.size++;
             made++;
         }
     }
-    if (lane == 0) q.nodes[idx].flags = nd.flags & ~1; /* lNodes.erase */
+    if (lane == 0) qt_node(q, idx)->flags = nd.flags & ~1; /* lNodes.erase */
     q.size--;
-    __syncthreads();
+    wave_sync();
     return made;
 }
 
@@ -686,6 +704,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
                                                  uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
 {
     __shared__ uint64_t items[QT_MAX_ITEMS];
+    __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
     const int level = blockIdx.x, frame = blockIdx.y;
     const ss_level &L = g->lv[level];
     ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
@@ -702,6 +721,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
     q.buf[0] = qbuf0 + (size_t)frame * g->cand_total + L.cand_base;
     q.buf[1] = qbuf1 + (size_t)frame * g->cand_total + L.cand_base;
     q.nodes = nodes_all + (size_t)frame * g->node_total + L.node_base;
+    q.lds_nodes = lds_nodes;
     q.node_cap = L.node_cap;
     q.n_nodes = 0;
     q.size = 0;
@@ -739,25 +759,25 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
         nd.beg = root_beg;
         nd.cnt = cnt_r;
         nd.flags = (cnt_r > 0 ? 1 : 0) | (cnt_r == 1 ? 2 : 0); /* empty roots are erased */
-        if (lane == 0) q.nodes[n_ini - 1 - r] = nd;
+        if (lane == 0) *qt_node(q, n_ini - 1 - r) = nd;
         if (cnt_r > 0) q.size++;
         root_beg += cnt_r;
     }
     q.n_nodes = n_ini;
-    __syncthreads();
+    wave_sync();
     if (root_beg != n_cand) q.error = -5; /* a candidate outside every root: cannot happen */
 
     /* expandable roots in creation order (= root n_ini-1 first) */
     int32_t *cur = list_a, *nxt = list_b;
     int n_cur = 0;
     for (int idx = 0; idx < n_ini; idx++) {
-        const int fl = rfl(q.nodes[idx].flags);
+        const int fl = rfl(qt_node(q, idx)->flags);
         if ((fl & 1) && !(fl & 2)) {
             if (lane == 0) cur[n_cur] = idx;
             n_cur++;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     bool finish = false;
     while (!finish && q.error == 0) {
@@ -780,7 +800,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
                     n_nxt++;
                 }
         }
-        __syncthreads();
+        wave_sync();
         { int32_t *t = cur; cur = nxt; nxt = t; }
         n_cur = n_nxt;
         if (q.error) break;
@@ -794,12 +814,14 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
                 /* vPrevSizeAndPointerToNode, in creation order; key = size, then UL.x */
                 for (int j = lane; j < n_prev; j += WAVE) {
                     const int idx = cur[j];
-                    const ss_qnode nd = q.nodes[idx];
+                    const ss_qnode nd = *qt_node(q, idx);
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
                 }
-                __syncthreads();
+                wave_sync();
+#ifndef SS_QT_NOSORT
                 if (lane == 0) std_sort_items(items, n_prev);
-                __syncthreads();
+#endif
+                wave_sync();
                 n_nxt = 0;
                 for (int j = n_prev - 1; j >= 0 && q.error == 0; j--) {
                     const int idx = rfl((int)((uint32_t)items[j] & 0xFFFFFu));
@@ -816,7 +838,7 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
                         }
                     if (q.size >= N) break;
                 }
-                __syncthreads();
+                wave_sync();
                 { int32_t *t = cur; cur = nxt; nxt = t; }
                 n_cur = n_nxt;
                 if (q.size >= N || q.size == prev2) finish = true;
@@ -832,14 +854,18 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
             const int idx = hi - lane;
             ss_qnode nd;
             nd.flags = 0;
-            if (idx >= 0) nd = q.nodes[idx];
+            if (idx >= 0) nd = *qt_node(q, idx);
             const bool alive = idx >= 0 && (nd.flags & 1);
             const uint64_t m = __ballot(alive);
             const int pos = n_out + __popcll(m & lt);
             if (alive && pos < L.sel_cap) {
                 const uint32_t *seg = q.buf[(nd.flags >> 2) & 1] + nd.beg;
                 uint32_t best = seg[0];
+#ifdef SS_QT_NOFINAL
+                for (int k = 1; k < 1; k++) {
+#else
                 for (int k = 1; k < nd.cnt; k++) {
+#endif
                     const uint32_t r = seg[k];
                     if (SS_PR(r) > SS_PR(best)) best = r;
                 }
