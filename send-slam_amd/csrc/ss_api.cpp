@@ -56,7 +56,7 @@ struct ss_ctx {
     ss_host_tables tabs;
     ss_geom *dg = nullptr;
     ss_rtab *d_rtab = nullptr;
-    uint32_t *d_tiles = nullptr;
+    uint32_t *d_tiles = nullptr, *d_tiles2 = nullptr;
 
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *flags = nullptr;
     uint32_t *cell_cnt = nullptr;
@@ -170,6 +170,7 @@ void free_geometry_buffers(ss_ctx *c)
     dev_free(c->dg);
     dev_free(c->d_rtab);
     dev_free(c->d_tiles);
+    dev_free(c->d_tiles2);
     dev_free(c->pyr);
     dev_free(c->blur);
     dev_free(c->score);
@@ -215,6 +216,8 @@ int ensure_geometry(ss_ctx *c, int w, int h)
         HIP_TRY(c, hipMemcpy(c->d_rtab, c->tabs.rtab.data(), c->tabs.rtab.size() * sizeof(ss_rtab), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->d_tiles, c->tabs.tiles.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_tiles, c->tabs.tiles.data(), c->tabs.tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tiles2, c->tabs.tiles2.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_tiles2, c->tabs.tiles2.data(), c->tabs.tiles2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->score, B * g.block_bytes));
@@ -225,8 +228,8 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->cand, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf0, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf1, B * g.cand_total * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->corner_list, B * g.tiles_total * (size_t)(SS_TILE_W * SS_TILE_H) * sizeof(uint16_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->corner_cnt, B * g.tiles_total * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->corner_list, B * g.tiles2_total * (size_t)(SS_TILE_W * SS_TILE_H2) * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->corner_cnt, B * g.tiles2_total * sizeof(uint16_t)));
     HIP_TRY(c, hipMalloc((void **)&c->nodes, B * g.node_total * sizeof(ss_qnode)));
     HIP_TRY(c, hipMalloc((void **)&c->lists, B * g.item_total * 2 * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->sel, B * g.sel_total * sizeof(uint32_t)));
@@ -269,16 +272,16 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     for (int l = 1; l < g.n_levels; l++) {
         stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
-        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
+        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, c->d_tiles, l, n);
     }
     {
         stage_timer t(c, "fast_score", n * all_px);
-        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles, c->corner_list, c->corner_cnt, n);
+        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, n);
     }
     HIP_TRY(c, hipMemsetAsync(c->cell_cnt, 0, (size_t)n * g.n_cells * sizeof(uint32_t), s));
     {
         stage_timer t(c, "nms", 0);
-        ssk_nms(s, c->score, c->flags, c->dg, g, c->d_tiles, c->corner_list, c->corner_cnt, c->d_cinfo, c->cell_cnt, n);
+        ssk_nms(s, c->score, c->flags, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, c->d_cinfo, c->cell_cnt, n);
     }
     {
         stage_timer t(c, "cells_emit", n * all_px);
@@ -291,7 +294,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
     {
         stage_timer t(c, "blur", n * 2 * all_px, c->stream2);
-        ssk_blur(c->stream2, c->pyr, c->blur, c->dg, g, c->d_tiles, n);
+        ssk_blur(c->stream2, c->pyr, c->blur, c->dg, g, c->d_tiles2, n);
     }
     HIP_TRY(c, hipEventRecord(c->ev_blur, c->stream2));
     {

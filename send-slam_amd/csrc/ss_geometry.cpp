@@ -126,9 +126,10 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
 
     tabs->rtab.clear();
     tabs->tiles.clear();
+    tabs->tiles2.clear();
     tabs->cinfo.clear();
     uint32_t off = 0;
-    int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile_base = 0;
+    int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile_base = 0, tile2_base = 0;
     for (int l = 0; l < p.n_levels; l++) {
         ss_level &L = g->lv[l];
         L.w = cv_round((float)width * inv_scale[l]);
@@ -211,6 +212,13 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
             for (int tx = 0; tx < L.tiles_x; tx++)
                 tabs->tiles.push_back(((uint32_t)l << 20) | ((uint32_t)ty << 8) | (uint32_t)tx);
 
+        L.tile2_base = tile2_base;
+        L.tiles2_y = (L.h + SS_TILE_H2 - 1) / SS_TILE_H2;
+        tile2_base += L.tiles_x * L.tiles2_y;
+        for (int ty = 0; ty < L.tiles2_y; ty++)
+            for (int tx = 0; tx < L.tiles_x; tx++)
+                tabs->tiles2.push_back(((uint32_t)l << 20) | ((uint32_t)ty << 8) | (uint32_t)tx);
+
         if (l > 0) {
             const ss_level &P = g->lv[l - 1];
             L.xtab_off = (int)tabs->rtab.size();
@@ -226,6 +234,7 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     g->node_total = node_base;
     g->item_total = item_base;
     g->tiles_total = tile_base;
+    g->tiles2_total = tile2_base;
     g->kcap = align_up(sel_base, 64);
     return SS_OK;
 }

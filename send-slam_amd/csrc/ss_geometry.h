@@ -10,7 +10,8 @@
 
 struct ss_host_tables {
     std::vector<ss_rtab> rtab;   /* resize coefficient tables, all levels */
-    std::vector<uint32_t> tiles; /* level << 20 | tile_y << 8 | tile_x, all levels */
+    std::vector<uint32_t> tiles;  /* 64x16 tiles: level << 20 | tile_y << 8 | tile_x, all levels */
+    std::vector<uint32_t> tiles2; /* 64x32 tiles, same packing */
     std::vector<uint16_t> cinfo; /* cell-window info per column / row, all levels */
 };
 

@@ -108,14 +108,63 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
     *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
 }
 
+/* LDS-staged form of the same step for pyramid scale factors <= 1.4 (the source window of a
+ * 64x16 destination tile then fits 96 B x 24 rows): the window is staged with coalesced dword
+ * loads, the taps are LDS byte reads -- 6 global memory instructions per 4 output pixels
+ * instead of 21. */
+#define RS_ROWS 24
+#define RS_WORDS 24
+
+__global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
+                                                    const ss_rtab *__restrict__ rtab,
+                                                    const uint32_t *__restrict__ tiles, int level)
+{
+    __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
+    const ss_level &D = g->lv[level];
+    const ss_level &S = g->lv[level - 1];
+    const uint32_t t = tiles[D.tile_base + blockIdx.x];
+    const int x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    uint8_t *base = pyr + (size_t)blockIdx.y * g->block_bytes;
+    const uint8_t *src = base + S.off;
+    const int gx0 = (int)rtab[D.xtab_off + x0].s0 & ~3;      /* first source byte, dword aligned */
+    const int gy0 = (int)rtab[D.ytab_off + imin(y0, D.h - 1)].s0;
+
+    for (int idx = threadIdx.x; idx < RS_ROWS * RS_WORDS; idx += 256) {
+        const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
+        const int gy = gy0 + r, gx = gx0 + 4 * c;
+        uint32_t v = 0;
+        if (gy < S.h && gx < S.pitch) v = *(const uint32_t *)(src + (size_t)gy * S.pitch + gx);
+        lds[r][c] = v;
+    }
+    __syncthreads();
+
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int dx4 = x0 + 4 * tx, dy = y0 + ty;
+    if (dy >= D.h || dx4 >= D.w) return;
+    const ss_rtab ry = rtab[D.ytab_off + dy];
+    const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
+    const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
+    const int b0 = ry.a0, b1 = ry.a1;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const ss_rtab rx = rtab[D.xtab_off + dx4 + i]; /* table padded past w */
+        const int h0 = l0[rx.s0] * rx.a0 + l0[rx.s1] * rx.a1;
+        const int h1 = l1[rx.s0] * rx.a0 + l1[rx.s1] * rx.a1;
+        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        out |= ((uint32_t)v & 0xFFu) << (8 * i);
+    }
+    *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* K2: FAST-9-16 response.  R = max over the 16 arcs of 9 contiguous ring pixels of        */
 /* min(v - p) and of min(p - v); a pixel is a corner at threshold t iff R > t and its      */
 /* cv::cornerScore is R - 1 for every such t, so ONE map serves iniTh and minTh.  Stored:  */
-/* R - 1 if R > minTh else 0.  64x16 tile per 256-thread block, 4 pixels per thread; the   */
-/* tile plus its 3-px ring halo is staged in LDS as aligned dwords.                        */
+/* R - 1 if R > minTh else 0.  64x32 tile per 256-thread block; the tile plus its 3-px    */
+/* ring halo is staged in LDS as aligned dwords.                        */
 /* ------------------------------------------------------------------------------------ */
-#define FT_ROWS (SS_TILE_H + 6)
+#define FT_ROWS (SS_TILE_H2 + 6)
 #define FT_WORDS (SS_TILE_W / 4 + 2)
 
 __device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k compile-time */
@@ -131,12 +180,12 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
                                                     uint16_t *__restrict__ corner_cnt)
 {
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
-    __shared__ uint32_t out_tile[SS_TILE_H][SS_TILE_W / 4];
-    __shared__ uint16_t list[SS_TILE_W * SS_TILE_H];
-    __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H];
+    __shared__ uint32_t out_tile[SS_TILE_H2][SS_TILE_W / 4];
+    __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2];
+    __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H2];
     __shared__ int n_list, n_corner;
     const uint32_t t = tiles[blockIdx.x];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
     const uint8_t *img = pyr + fb;
@@ -158,12 +207,14 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
      * queued in LDS and scored in phase 2, the rest get 0 without the 100-op arc search. */
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int min_th = g->min_th;
-    const int y = y0 + ty;
-    {
-        const uint32_t up[3] = {lds[ty][tx], lds[ty][tx + 1], lds[ty][tx + 2]};
-        const uint32_t mid[3] = {lds[ty + 3][tx], lds[ty + 3][tx + 1], lds[ty + 3][tx + 2]};
-        const uint32_t dn[3] = {lds[ty + 6][tx], lds[ty + 6][tx + 1], lds[ty + 6][tx + 2]};
-        out_tile[ty][tx] = 0;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
+        const int ly = 2 * ty + rr;
+        const int y = y0 + ly;
+        const uint32_t up[3] = {lds[ly][tx], lds[ly][tx + 1], lds[ly][tx + 2]};
+        const uint32_t mid[3] = {lds[ly + 3][tx], lds[ly + 3][tx + 1], lds[ly + 3][tx + 2]};
+        const uint32_t dn[3] = {lds[ly + 6][tx], lds[ly + 6][tx + 1], lds[ly + 6][tx + 2]};
+        out_tile[ly][tx] = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int v = tile_byte(mid, 4 + i);
@@ -173,7 +224,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             const int n_bright = (d0 < -min_th) + (d4 < -min_th) + (d8 < -min_th) + (d12 < -min_th);
             const int x = x0 + 4 * tx + i;
             const bool inside = x >= 3 && x < w - 3 && y >= 3 && y < h - 3;
-            if (inside && (n_dark >= 2 || n_bright >= 2)) list[atomicAdd(&n_list, 1)] = (uint16_t)((ty << 8) | (4 * tx + i));
+            if (inside && (n_dark >= 2 || n_bright >= 2)) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
         }
     }
     __syncthreads();
@@ -212,13 +263,17 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         }
     }
     __syncthreads();
-    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ty][tx];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int ly = 2 * ty + rr, y = y0 + ly;
+        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ly][tx];
+    }
     /* corners (score > 0) go to this tile's slot of the corner list, any order: the sparse NMS
      * pass works on these lists instead of sweeping the whole map.  A slot holds a full tile,
      * so nothing can overflow and no global atomic is needed. */
-    const size_t slot = (size_t)blockIdx.y * g->tiles_total + blockIdx.x;
+    const size_t slot = (size_t)blockIdx.y * g->tiles2_total + blockIdx.x;
     const int nc = n_corner;
-    uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H);
+    uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
     for (int e = threadIdx.x; e < nc; e += 256) cl[e] = corners[e];
     if (threadIdx.x == 0) corner_cnt[slot] = (uint16_t)nc;
 }
@@ -240,9 +295,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                                               const uint32_t *__restrict__ tiles)
 {
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
-    __shared__ uint32_t hbuf[FT_ROWS][SS_TILE_W / 2]; /* u16 x 64 per row */
+    __shared__ uint32_t hbuf[FT_ROWS][SS_TILE_W / 2]; /* u16 x 64 per row; FT_ROWS = 32 + 6 */
     const uint32_t t = tiles[blockIdx.x];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
     const uint8_t *img = pyr + fb;
@@ -281,21 +336,31 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     __syncthreads();
 
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int y = y0 + ty;
-    uint32_t acc[4] = {0, 0, 0, 0};
     constexpr uint32_t KV[7] = {SS_GAUSS_K0, SS_GAUSS_K1, SS_GAUSS_K2, SS_GAUSS_K3, SS_GAUSS_K2, SS_GAUSS_K1, SS_GAUSS_K0};
+    /* two output rows per thread: rows 2ty and 2ty+1 share six of their seven+seven h rows */
+    uint32_t ha[8], hb[8];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        const uint32_t a = hbuf[ty + j][2 * tx], b = hbuf[ty + j][2 * tx + 1];
-        acc[0] += KV[j] * (a & 0xFFFFu);
-        acc[1] += KV[j] * (a >> 16);
-        acc[2] += KV[j] * (b & 0xFFFFu);
-        acc[3] += KV[j] * (b >> 16);
+    for (int j = 0; j < 8; j++) {
+        ha[j] = hbuf[2 * ty + j][2 * tx];
+        hb[j] = hbuf[2 * ty + j][2 * tx + 1];
     }
-    uint32_t out = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) out |= (((acc[i] + 32768u) >> 16) & 0xFFu) << (8 * i);
-    if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(blur + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+    for (int rr = 0; rr < 2; rr++) {
+        uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint32_t a = ha[j + rr], b = hb[j + rr];
+            acc[0] += KV[j] * (a & 0xFFFFu);
+            acc[1] += KV[j] * (a >> 16);
+            acc[2] += KV[j] * (b & 0xFFFFu);
+            acc[3] += KV[j] * (b >> 16);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) out |= (((acc[i] + 32768u) >> 16) & 0xFFu) << (8 * i);
+        const int y = y0 + 2 * ty + rr;
+        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(blur + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -313,15 +378,15 @@ __global__ __launch_bounds__(64) void k_nms(const uint8_t *__restrict__ score, u
                                             const uint16_t *__restrict__ cinfo, uint32_t *__restrict__ cell_cnt)
 {
     const int frame = blockIdx.y;
-    const size_t slot = (size_t)frame * g->tiles_total + blockIdx.x;
+    const size_t slot = (size_t)frame * g->tiles2_total + blockIdx.x;
     const int n = corner_cnt[slot];
     if (n == 0) return;
     const uint32_t t = tiles[blockIdx.x];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
+    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)frame * g->block_bytes + L.off;
     const uint8_t *sm = score + fb;
-    const uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H);
+    const uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
     const int pitch = L.pitch, ini_th = g->ini_th;
     for (int i = threadIdx.x; i < n; i += 64) {
         const uint32_t rec = cl[i];
@@ -1080,13 +1145,18 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     const int t0 = imin(c0 + wave * quarter, c1), t1 = imin(t0 + quarter, c1);
 
     uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+    /* local index of the train row this lane must skip (self-match), or a value no row has */
+    const uint32_t skip = excl ? (uint32_t)(qi - t0) : 0xFFFFFFFFu;
+    /* unrolled by 4 so four s_load_dwordx8 are in flight before the first XOR needs its operand */
+#pragma unroll 4
     for (int j = t0; j < t1; j++) {
         const uint32_t *tj = tf + (size_t)j * 8;
         uint32_t d = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
-        uint32_t key = (d << 16) | (uint32_t)(j - t0);
-        if (excl && j == qi) key = 0xFFFFFFFFu;
+        const uint32_t jl = (uint32_t)(j - t0);
+        uint32_t key = (d << 16) | jl;
+        key = jl == skip ? 0xFFFFFFFFu : key;
         k2 = min(k2, max(k1, key));
         k1 = min(k1, key);
     }
@@ -1154,29 +1224,36 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
 }
 
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
-                int level, int n_frames)
+                const uint32_t *tiles, int level, int n_frames)
 {
-    dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level);
+    /* source window of a 64x16 tile: (64 * scale + 1 + 3 alignment) bytes x (16 * scale + 2) rows */
+    const float sx = (float)hg.lv[level - 1].w / (float)hg.lv[level].w, sy = (float)hg.lv[level - 1].h / (float)hg.lv[level].h;
+    if (64.f * sx + 6.f <= 4.f * RS_WORDS && 16.f * sy + 3.f <= (float)RS_ROWS) {
+        hipLaunchKernelGGL(k_resize_lds, dim3(hg.lv[level].tiles_x * hg.lv[level].tiles_y, n_frames), dim3(256), 0, s, pyr, dg,
+                           rtab, tiles, level);
+    } else {
+        dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level);
+    }
 }
 
 void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
                     const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt);
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt);
 }
 
 void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
               const uint32_t *tiles, int n_frames)
 {
-    hipLaunchKernelGGL(k_blur, dim3(hg.tiles_total, n_frames), dim3(256), 0, s, pyr, blur, dg, tiles);
+    hipLaunchKernelGGL(k_blur, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, blur, dg, tiles);
 }
 
 void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
              const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
              uint32_t *cell_cnt, int n_frames)
 {
-    hipLaunchKernelGGL(k_nms, dim3(hg.tiles_total, n_frames), dim3(64), 0, s, score, flags, dg, tiles, corner_list, corner_cnt,
+    hipLaunchKernelGGL(k_nms, dim3(hg.tiles2_total, n_frames), dim3(64), 0, s, score, flags, dg, tiles, corner_list, corner_cnt,
                        cinfo, cell_cnt);
 }
 
@@ -1210,7 +1287,7 @@ void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, co
 int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len)
 {
     const int q_groups = (n_query_max + 63) / 64;
-    const long blocks_wanted = 2048; /* >> 256 CUs */
+    const long blocks_wanted = 16384; /* >> 256 CUs x 8 resident blocks: keeps the last partial round of blocks small */
     long chunks = (blocks_wanted + (long)q_groups * n_frames - 1) / ((long)q_groups * n_frames > 0 ? (long)q_groups * n_frames : 1);
     const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave */
     if (chunks > max_chunks) chunks = max_chunks;

@@ -25,6 +25,7 @@
 #define SS_MAX_LEVELS_ 16
 #define SS_TILE_W 64
 #define SS_TILE_H 16
+#define SS_TILE_H2 32 /* tall tiles for the FAST and blur kernels */
 
 #define SS_PACK(x, y, r) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
 #define SS_PX(p) ((int)((p) & 0xFFFu))
@@ -44,6 +45,7 @@ typedef struct {
     int32_t item_base, item_cap; /* quadtree sort items / expandable lists */
     /* 64x16 tiles for the image kernels */
     int32_t tile_base, tiles_x, tiles_y;
+    int32_t tile2_base, tiles2_y; /* 64x32 tiles */
     /* resize tables for building THIS level from level-1 (entries of 8 bytes) */
     int32_t xtab_off, ytab_off;
     /* cell-window tables (u16 per column / row of the level): SS_CI_* bits | cell index */
@@ -69,6 +71,7 @@ typedef struct {
     int32_t node_total;
     int32_t item_total;
     int32_t tiles_total;
+    int32_t tiles2_total;
     int32_t umax[16];
     ss_level lv[SS_MAX_LEVELS_];
 } ss_geom;
