@@ -272,7 +272,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     for (int l = 1; l < g.n_levels; l++) {
         stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
-        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, c->d_tiles, l, n);
+        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
     }
     {
         stage_timer t(c, "fast_score", n * all_px);

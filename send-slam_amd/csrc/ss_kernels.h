@@ -11,7 +11,7 @@
 void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride, int64_t frame_stride,
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
-                const uint32_t *tiles, int level, int n_frames);
+                int level, int n_frames);
 void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
                     const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames);
 void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,

@@ -109,52 +109,61 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 }
 
 /* LDS-staged form of the same step for pyramid scale factors <= 1.4 (the source window of a
- * 64x16 destination tile then fits 96 B x 24 rows): the window is staged with coalesced dword
+ * 64x64 destination tile then fits 96 B x 80 rows): the window is staged with coalesced dword
  * loads, the taps are LDS byte reads -- 6 global memory instructions per 4 output pixels
  * instead of 21. */
-#define RS_ROWS 24
+#define RS_TILE_H 64
+#define RS_ROWS 80 /* 64 * 1.2 + 2 rounded up */
 #define RS_WORDS 24
 
 __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
-                                                    const ss_rtab *__restrict__ rtab,
-                                                    const uint32_t *__restrict__ tiles, int level)
+                                                    const ss_rtab *__restrict__ rtab, int level)
 {
     __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
+    __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
-    const uint32_t t = tiles[D.tile_base + blockIdx.x];
-    const int x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H;
-    uint8_t *base = pyr + (size_t)blockIdx.y * g->block_bytes;
+    const int x0 = blockIdx.x * SS_TILE_W, y0 = blockIdx.y * RS_TILE_H;
+    uint8_t *base = pyr + (size_t)blockIdx.z * g->block_bytes;
     const uint8_t *src = base + S.off;
+    /* the tile's tap tables go to LDS too (x table is padded past w; y rows are clamped) */
+    if (threadIdx.x < SS_TILE_W) xt[threadIdx.x] = rtab[D.xtab_off + x0 + threadIdx.x];
+    else if (threadIdx.x < SS_TILE_W + RS_TILE_H) yt[threadIdx.x - SS_TILE_W] = rtab[D.ytab_off + imin(y0 + (int)threadIdx.x - SS_TILE_W, D.h - 1)];
     const int gx0 = (int)rtab[D.xtab_off + x0].s0 & ~3;      /* first source byte, dword aligned */
     const int gy0 = (int)rtab[D.ytab_off + imin(y0, D.h - 1)].s0;
+    const int gy1 = (int)rtab[D.ytab_off + imin(y0 + RS_TILE_H - 1, D.h - 1)].s1; /* last source row used */
 
     for (int idx = threadIdx.x; idx < RS_ROWS * RS_WORDS; idx += 256) {
         const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
         const int gy = gy0 + r, gx = gx0 + 4 * c;
-        uint32_t v = 0;
-        if (gy < S.h && gx < S.pitch) v = *(const uint32_t *)(src + (size_t)gy * S.pitch + gx);
-        lds[r][c] = v;
+        if (gy <= gy1 && gx < S.pitch) lds[r][c] = *(const uint32_t *)(src + (size_t)gy * S.pitch + gx);
     }
     __syncthreads();
 
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int dx4 = x0 + 4 * tx, dy = y0 + ty;
-    if (dy >= D.h || dx4 >= D.w) return;
-    const ss_rtab ry = rtab[D.ytab_off + dy];
-    const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
-    const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
-    const int b0 = ry.a0, b1 = ry.a1;
-    uint32_t out = 0;
+    const int dx4 = x0 + 4 * tx;
+    if (dx4 >= D.w) return;
+    ss_rtab rx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const ss_rtab rx = rtab[D.xtab_off + dx4 + i]; /* table padded past w */
-        const int h0 = l0[rx.s0] * rx.a0 + l0[rx.s1] * rx.a1;
-        const int h1 = l1[rx.s0] * rx.a0 + l1[rx.s1] * rx.a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        out |= ((uint32_t)v & 0xFFu) << (8 * i);
+    for (int i = 0; i < 4; i++) rx[i] = xt[4 * tx + i];
+#pragma unroll
+    for (int rr = 0; rr < RS_TILE_H / 16; rr++) {
+        const int ly = ty + 16 * rr, dy = y0 + ly;
+        if (dy >= D.h) break;
+        const ss_rtab ry = yt[ly];
+        const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
+        const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
+        const int b0 = ry.a0, b1 = ry.a1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int h0 = l0[rx[i].s0] * rx[i].a0 + l0[rx[i].s1] * rx[i].a1;
+            const int h1 = l1[rx[i].s0] * rx[i].a0 + l1[rx[i].s1] * rx[i].a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= ((uint32_t)v & 0xFFu) << (8 * i);
+        }
+        *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
     }
-    *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
 /* pairs L, L+64, L+128, L+192; __ballot(t0 < t1) IS descriptor bytes 8k .. 8k+7 (bit i of  */
 /* byte j = test 8j+i).                                                                    */
 /* ------------------------------------------------------------------------------------ */
-__constant__ int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
 
 __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur,
@@ -1025,14 +1034,26 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     const size_t fb = (size_t)frame * g->block_bytes + L.off;
     const int pitch = L.pitch;
 
-    /* IC_Angle */
+    /* IC_Angle: the 31-row patch around the keypoint is staged in LDS as aligned dwords
+     * (5 coalesced loads per lane instead of 16 byte gathers); lane = (row, half) of the disc */
+    __shared__ uint32_t patch_all[4][31][10];
+    uint32_t(*patch)[10] = patch_all[threadIdx.x >> 6];
+    const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
+    {
+        const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
+        for (int idx = lane; idx < 31 * 10; idx += WAVE) {
+            const int r = idx / 10, c = idx - r * 10;
+            patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
+        }
+    }
+    wave_sync();
     int m10 = 0, m01 = 0;
     {
         const int row = lane & 31, half = lane >> 5;
         if (row < 31) {
             const int v = row - SS_HALF_PATCH;
             const int d = g->umax[v < 0 ? -v : v];
-            const uint8_t *p = pyr + fb + (size_t)(ky + v) * pitch + kx;
+            const uint8_t *p = (const uint8_t *)&patch[row][0] + (kx - px0);
             const int u0 = half ? 0 : -d, u1 = half ? d : -1;
             int rs = 0;
             for (int u = u0; u <= u1; u++) {
@@ -1054,8 +1075,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     uint64_t words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int8_t *pt = c_pattern + 4 * (lane + 64 * k);
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const uint32_t pt = *(const uint32_t *)(c_pattern + 4 * (lane + 64 * k)); /* x0 y0 x1 y1 as int8 */
+        const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
@@ -1224,13 +1246,13 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
 }
 
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
-                const uint32_t *tiles, int level, int n_frames)
+                int level, int n_frames)
 {
-    /* source window of a 64x16 tile: (64 * scale + 1 + 3 alignment) bytes x (16 * scale + 2) rows */
+    /* source window of a 64x64 tile: (64 * scale + 1 + 3 alignment) bytes x (64 * scale + 2) rows */
     const float sx = (float)hg.lv[level - 1].w / (float)hg.lv[level].w, sy = (float)hg.lv[level - 1].h / (float)hg.lv[level].h;
-    if (64.f * sx + 6.f <= 4.f * RS_WORDS && 16.f * sy + 3.f <= (float)RS_ROWS) {
-        hipLaunchKernelGGL(k_resize_lds, dim3(hg.lv[level].tiles_x * hg.lv[level].tiles_y, n_frames), dim3(256), 0, s, pyr, dg,
-                           rtab, tiles, level);
+    if (64.f * sx + 6.f <= 4.f * RS_WORDS && (float)RS_TILE_H * sy + 3.f <= (float)RS_ROWS) {
+        dim3 grid((hg.lv[level].w + SS_TILE_W - 1) / SS_TILE_W, (hg.lv[level].h + RS_TILE_H - 1) / RS_TILE_H, n_frames);
+        hipLaunchKernelGGL(k_resize_lds, grid, dim3(256), 0, s, pyr, dg, rtab, level);
     } else {
         dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level);
