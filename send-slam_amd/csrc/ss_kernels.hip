@@ -43,6 +43,17 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int min3(int a, int b, int c) { return imin(imin(a, b), c); }
 __device__ __forceinline__ int max3(int a, int b, int c) { return imax(imax(a, b), c); }
 
+/* XCD-aware block index (cdna guide T1): workgroups are dealt round-robin over the 8 XCDs, each
+ * with its own L2, so blockIdx b and b+1 never share an L2.  This bijective remap gives every XCD
+ * one CONTIGUOUS range of logical indices: horizontally adjacent tiles / cells (consecutive
+ * logical index) then run on the same XCD and share the 64-B sectors their halos overlap on.
+ * Placement only changes speed, never results. */
+__device__ __forceinline__ int xcd_remap(int bid, int n)
+{
+    const int q = n >> 3, r = n & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -123,8 +134,10 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
-    const int x0 = blockIdx.x * SS_TILE_W, y0 = blockIdx.y * RS_TILE_H;
-    uint8_t *base = pyr + (size_t)blockIdx.z * g->block_bytes;
+    const int tiles_x = (D.w + SS_TILE_W - 1) / SS_TILE_W;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int x0 = (tile % tiles_x) * SS_TILE_W, y0 = (tile / tiles_x) * RS_TILE_H;
+    uint8_t *base = pyr + (size_t)blockIdx.y * g->block_bytes;
     const uint8_t *src = base + S.off;
     /* the tile's tap tables go to LDS too (x table is padded past w; y rows are clamped) */
     if (threadIdx.x < SS_TILE_W) xt[threadIdx.x] = rtab[D.xtab_off + x0 + threadIdx.x];
@@ -193,7 +206,8 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2];
     __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H2];
     __shared__ int n_list, n_corner;
-    const uint32_t t = tiles[blockIdx.x];
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const uint32_t t = tiles[tile];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     /* corners (score > 0) go to this tile's slot of the corner list, any order: the sparse NMS
      * pass works on these lists instead of sweeping the whole map.  A slot holds a full tile,
      * so nothing can overflow and no global atomic is needed. */
-    const size_t slot = (size_t)blockIdx.y * g->tiles2_total + blockIdx.x;
+    const size_t slot = (size_t)blockIdx.y * g->tiles2_total + tile;
     const int nc = n_corner;
     uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
     for (int e = threadIdx.x; e < nc; e += 256) cl[e] = corners[e];
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
     __shared__ uint32_t hbuf[FT_ROWS][SS_TILE_W / 2]; /* u16 x 64 per row; FT_ROWS = 32 + 6 */
-    const uint32_t t = tiles[blockIdx.x];
+    const uint32_t t = tiles[xcd_remap((int)blockIdx.x, (int)gridDim.x)];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
@@ -387,10 +401,11 @@ __global__ __launch_bounds__(64) void k_nms(const uint8_t *__restrict__ score, u
                                             const uint16_t *__restrict__ cinfo, uint32_t *__restrict__ cell_cnt)
 {
     const int frame = blockIdx.y;
-    const size_t slot = (size_t)frame * g->tiles2_total + blockIdx.x;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const size_t slot = (size_t)frame * g->tiles2_total + tile;
     const int n = corner_cnt[slot];
     if (n == 0) return;
-    const uint32_t t = tiles[blockIdx.x];
+    const uint32_t t = tiles[tile];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)frame * g->block_bytes + L.off;
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(64) void k_cells_emit(const uint8_t *__restrict__ s
                                                    const ss_geom *__restrict__ g, const uint32_t *__restrict__ cell_cnt,
                                                    uint32_t *__restrict__ cand, ss_level_state *__restrict__ state)
 {
-    const int frame = blockIdx.y, cell = blockIdx.x;
+    const int frame = blockIdx.y, cell = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int level = 0;
     for (int l = 1; l < g->n_levels; l++)
         if (cell >= g->lv[l].cell_base) level = l;
@@ -1251,7 +1266,7 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
     /* source window of a 64x64 tile: (64 * scale + 1 + 3 alignment) bytes x (64 * scale + 2) rows */
     const float sx = (float)hg.lv[level - 1].w / (float)hg.lv[level].w, sy = (float)hg.lv[level - 1].h / (float)hg.lv[level].h;
     if (64.f * sx + 6.f <= 4.f * RS_WORDS && (float)RS_TILE_H * sy + 3.f <= (float)RS_ROWS) {
-        dim3 grid((hg.lv[level].w + SS_TILE_W - 1) / SS_TILE_W, (hg.lv[level].h + RS_TILE_H - 1) / RS_TILE_H, n_frames);
+        dim3 grid(((hg.lv[level].w + SS_TILE_W - 1) / SS_TILE_W) * ((hg.lv[level].h + RS_TILE_H - 1) / RS_TILE_H), n_frames);
         hipLaunchKernelGGL(k_resize_lds, grid, dim3(256), 0, s, pyr, dg, rtab, level);
     } else {
         dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
