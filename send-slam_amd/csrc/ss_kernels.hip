@@ -213,27 +213,37 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
     const uint8_t *img = pyr + fb;
     const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
-    for (int idx = threadIdx.x; idx < FT_ROWS * FT_WORDS; idx += 256) {
-        const int r = idx / FT_WORDS, c = idx - r * FT_WORDS;
-        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
-        uint32_t v = 0;
-        if (gy >= 0 && gy < h && gx >= 0 && gx < pitch) v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
-        lds[r][c] = v;
+    /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
+     * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2 */
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        const int r = ty + 16 * rr;
+        if (r < FT_ROWS) {
+            const int gy = y0 - 3 + r;
+            const bool row_ok = gy >= 0 && gy < h;
+            const uint8_t *row = img + (size_t)gy * pitch;
+            const int gx = x0 - 4 + 4 * tx;
+            lds[r][tx] = (row_ok && gx >= 0 && gx < pitch) ? *(const uint32_t *)(row + gx) : 0u;
+            if (tx < 2) {
+                const int gx2 = x0 + 60 + 4 * tx;
+                lds[r][16 + tx] = (row_ok && gx2 < pitch) ? *(const uint32_t *)(row + gx2) : 0u;
+            }
+        }
     }
     __syncthreads();
 
-    /* Phase 1, every pixel: the compass test.  Any 9 contiguous ring pixels contain >= 2 of the
-     * 4 compass points (ring 0, 4, 8, 12), so a corner at threshold t needs >= 2 compass points
-     * darker than v - t or >= 2 brighter than v + t.  Only a few % of the pixels pass; they are
-     * queued in LDS and scored in phase 2, the rest get 0 without the 100-op arc search. */
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    /* Phase 1, every pixel: the compass test of cv::FAST.  Any 9 contiguous ring pixels contain
+     * at least one pixel of every opposing pair {k, k+8}; with the pairs (0,8) and (4,12): a
+     * corner at threshold t needs (d0 > t or d8 > t) and (d4 > t or d12 > t), or the same with
+     * d < -t.  Only a few % of the pixels pass; they are queued in LDS and scored in phase 2,
+     * the rest get 0 without the 100-op arc search. */
     const int min_th = g->min_th;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
-        const int y = y0 + ly;
         const uint32_t up[3] = {lds[ly][tx], lds[ly][tx + 1], lds[ly][tx + 2]};
         const uint32_t mid[3] = {lds[ly + 3][tx], lds[ly + 3][tx + 1], lds[ly + 3][tx + 2]};
         const uint32_t dn[3] = {lds[ly + 6][tx], lds[ly + 6][tx + 1], lds[ly + 6][tx + 2]};
@@ -243,11 +253,12 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             const int v = tile_byte(mid, 4 + i);
             const int d0 = v - tile_byte(dn, 4 + i), d8 = v - tile_byte(up, 4 + i);
             const int d4 = v - tile_byte(mid, 7 + i), d12 = v - tile_byte(mid, 1 + i);
-            const int n_dark = (d0 > min_th) + (d4 > min_th) + (d8 > min_th) + (d12 > min_th);
-            const int n_bright = (d0 < -min_th) + (d4 < -min_th) + (d8 < -min_th) + (d12 < -min_th);
-            const int x = x0 + 4 * tx + i;
-            const bool inside = x >= 3 && x < w - 3 && y >= 3 && y < h - 3;
-            if (inside && (n_dark >= 2 || n_bright >= 2)) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
+            const bool cand = (imax(d0, d8) > min_th && imax(d4, d12) > min_th) ||
+                              (imin(d0, d8) < -min_th && imin(d4, d12) < -min_th);
+            if (cand) {
+                const int x = x0 + 4 * tx + i, y = y0 + ly;
+                if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
+            }
         }
     }
     __syncthreads();
@@ -313,76 +324,92 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p < 0 ? 0 : (p >= n ? n - 1 : p);
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               const ss_geom *__restrict__ g,
                                               const uint32_t *__restrict__ tiles)
 {
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
-    __shared__ uint32_t hbuf[FT_ROWS][SS_TILE_W / 2]; /* u16 x 64 per row; FT_ROWS = 32 + 6 */
+    /* horizontal sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel so the
+     * vertical pass is four v_dot2_u32_u16 per output */
+    __shared__ uint32_t hpair[FT_ROWS / 2][SS_TILE_W];
     const uint32_t t = tiles[xcd_remap((int)blockIdx.x, (int)gridDim.x)];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
     const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
     const uint8_t *img = pyr + fb;
     const int w = L.w, h = L.h, pitch = L.pitch;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 
-    for (int idx = threadIdx.x; idx < FT_ROWS * FT_WORDS; idx += 256) {
-        const int r = idx / FT_WORDS, c = idx - r * FT_WORDS;
-        const int gy = y0 - 3 + r, gx = x0 - 4 + 4 * c;
-        uint32_t v;
-        if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
-            v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
-        } else {
-            const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
-            v = 0;
+    /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67, BORDER_REFLECT_101 applied here */
 #pragma unroll
-            for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+    for (int rr = 0; rr < 3; rr++) {
+        const int r = ty + 16 * rr;
+        if (r < FT_ROWS) {
+            const int gy = y0 - 3 + r;
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const int c = cc == 0 ? tx : 16 + tx;
+                if (cc == 1 && tx >= 2) break;
+                const int gx = x0 - 4 + 4 * c;
+                uint32_t v;
+                if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
+                    v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
+                } else {
+                    const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
+                    v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+                }
+                lds[r][c] = v;
+            }
         }
-        lds[r][c] = v;
     }
     __syncthreads();
 
+    /* horizontal pass: 7 taps = two v_dot4_u32_u8 on the byte window [x-3, x+4] */
+    constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
+    constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
+    uint16_t *h16 = (uint16_t *)&hpair[0][0];
     for (int idx = threadIdx.x; idx < FT_ROWS * 16; idx += 256) {
         const int r = idx >> 4, q = idx & 15;
-        const uint32_t rw[3] = {lds[r][q], lds[r][q + 1], lds[r][q + 2]};
+        const uint32_t w0 = lds[r][q], w1 = lds[r][q + 1], w2 = lds[r][q + 2];
         uint32_t hv[4];
+        hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
+        hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
+        hv[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
+        hv[3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
+        uint16_t *dst = h16 + ((size_t)(r >> 1) * SS_TILE_W + 4 * q) * 2 + (r & 1);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            hv[i] = (uint32_t)(SS_GAUSS_K0 * (tile_byte(rw, 1 + i) + tile_byte(rw, 7 + i)) +
-                               SS_GAUSS_K1 * (tile_byte(rw, 2 + i) + tile_byte(rw, 6 + i)) +
-                               SS_GAUSS_K2 * (tile_byte(rw, 3 + i) + tile_byte(rw, 5 + i)) +
-                               SS_GAUSS_K3 * tile_byte(rw, 4 + i));
-        }
-        hbuf[r][2 * q] = hv[0] | (hv[1] << 16);
-        hbuf[r][2 * q + 1] = hv[2] | (hv[3] << 16);
+        for (int i = 0; i < 4; i++) dst[2 * i] = (uint16_t)hv[i];
     }
     __syncthreads();
 
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    constexpr uint32_t KV[7] = {SS_GAUSS_K0, SS_GAUSS_K1, SS_GAUSS_K2, SS_GAUSS_K3, SS_GAUSS_K2, SS_GAUSS_K1, SS_GAUSS_K0};
-    /* two output rows per thread: rows 2ty and 2ty+1 share six of their seven+seven h rows */
-    uint32_t ha[8], hb[8];
+    /* vertical pass, two output rows per thread: rows 2ty and 2ty+1 read the same four row pairs */
+    constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
+    constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
+    constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
+    constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
+    uint32_t out_a = 0, out_b = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        ha[j] = hbuf[2 * ty + j][2 * tx];
-        hb[j] = hbuf[2 * ty + j][2 * tx + 1];
+    for (int i = 0; i < 4; i++) {
+        const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
+        const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
+        const uint32_t a = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
+        const uint32_t b = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
+        out_a |= ((a >> 16) & 0xFFu) << (8 * i);
+        out_b |= ((b >> 16) & 0xFFu) << (8 * i);
     }
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        uint32_t acc[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const uint32_t a = ha[j + rr], b = hb[j + rr];
-            acc[0] += KV[j] * (a & 0xFFFFu);
-            acc[1] += KV[j] * (a >> 16);
-            acc[2] += KV[j] * (b & 0xFFFFu);
-            acc[3] += KV[j] * (b >> 16);
-        }
-        uint32_t out = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) out |= (((acc[i] + 32768u) >> 16) & 0xFFu) << (8 * i);
-        const int y = y0 + 2 * ty + rr;
-        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(blur + fb + (size_t)y * pitch + x0 + 4 * tx) = out;
+    const int ya = y0 + 2 * ty;
+    if (x0 + 4 * tx < pitch) {
+        if (ya < h) *(uint32_t *)(blur + fb + (size_t)ya * pitch + x0 + 4 * tx) = out_a;
+        if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
     }
 }
 
