@@ -189,6 +189,9 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 #define FT_ROWS (SS_TILE_H2 + 6)
 #define FT_WORDS (SS_TILE_W / 4 + 2)
 
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
+
 __device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k compile-time */
 {
     return (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
@@ -244,20 +247,32 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
-        const uint32_t up[3] = {lds[ly][tx], lds[ly][tx + 1], lds[ly][tx + 2]};
-        const uint32_t mid[3] = {lds[ly + 3][tx], lds[ly + 3][tx + 1], lds[ly + 3][tx + 2]};
-        const uint32_t dn[3] = {lds[ly + 6][tx], lds[ly + 6][tx + 1], lds[ly + 6][tx + 2]};
+        /* two pixels per operation: ring values go to the 16-bit halves of a dword (v_perm_b32),
+         * differences and the min/max tree are v_pk_*_i16 */
+        const uint32_t u1 = lds[ly][tx + 1], n1 = lds[ly + 6][tx + 1];
+        const uint32_t m0 = lds[ly + 3][tx], m1 = lds[ly + 3][tx + 1], m2 = lds[ly + 3][tx + 2];
         out_tile[ly][tx] = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int v = tile_byte(mid, 4 + i);
-            const int d0 = v - tile_byte(dn, 4 + i), d8 = v - tile_byte(up, 4 + i);
-            const int d4 = v - tile_byte(mid, 7 + i), d12 = v - tile_byte(mid, 1 + i);
-            const bool cand = (imax(d0, d8) > min_th && imax(d4, d12) > min_th) ||
-                              (imin(d0, d8) < -min_th && imin(d4, d12) < -min_th);
-            if (cand) {
-                const int x = x0 + 4 * tx + i, y = y0 + ly;
-                if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
+        for (int pr = 0; pr < 2; pr++) { /* pixels 2pr, 2pr+1 of the thread's four */
+            constexpr uint32_t Z = 0x0C000C00u; /* selector bytes 1 and 3 = constant 0 */
+            const uint32_t sel_c = Z | (uint32_t)(2 * pr) | ((uint32_t)(2 * pr + 1) << 16);  /* bytes 2pr, 2pr+1 of one dword */
+            const i16x2 v = as_i16x2(__builtin_amdgcn_perm(0u, m1, sel_c));
+            const i16x2 pu = as_i16x2(__builtin_amdgcn_perm(0u, u1, sel_c));
+            const i16x2 pd = as_i16x2(__builtin_amdgcn_perm(0u, n1, sel_c));
+            /* x+3: window bytes 7+2pr, 8+2pr = bytes 3+2pr, 4+2pr of {m2:m1}; x-3: bytes 1+2pr, 2+2pr of {m1:m0} */
+            const i16x2 pr3 = as_i16x2(__builtin_amdgcn_perm(m2, m1, Z | (uint32_t)(3 + 2 * pr) | ((uint32_t)(4 + 2 * pr) << 16)));
+            const i16x2 pl3 = as_i16x2(__builtin_amdgcn_perm(m1, m0, Z | (uint32_t)(1 + 2 * pr) | ((uint32_t)(2 + 2 * pr) << 16)));
+            const i16x2 d0 = v - pd, d8 = v - pu, d4 = v - pr3, d12 = v - pl3;
+            const i16x2 dark = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12));
+            const i16x2 bright = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12));
+            const i16x2 c = __builtin_elementwise_max(dark, (i16x2)(0) - bright);
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                if ((int)c[hh] > min_th) {
+                    const int i = 2 * pr + hh;
+                    const int x = x0 + 4 * tx + i, y = y0 + ly;
+                    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
+                }
             }
         }
     }
@@ -1209,20 +1224,33 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     const int t0 = imin(c0 + wave * quarter, c1), t1 = imin(t0 + quarter, c1);
 
     uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    /* local index of the train row this lane must skip (self-match), or a value no row has */
-    const uint32_t skip = excl ? (uint32_t)(qi - t0) : 0xFFFFFFFFu;
-    /* unrolled by 4 so four s_load_dwordx8 are in flight before the first XOR needs its operand */
+    /* 16 VALU per pair for the distance (XOR + popcount-accumulate with SGPR operands) + 4 to
+     * keep the two smallest keys.  Only the <= 64 train rows whose index equals one of this
+     * wave's query indices can be a self pair: the loop is split so the other rows skip the
+     * j == i test.  Unrolled by 4 so several s_load_dwordx8 are in flight. */
+    auto scan = [&](int ja, int jb, bool check_self) {
+        const uint32_t skip = (uint32_t)(qi - t0);
 #pragma unroll 4
-    for (int j = t0; j < t1; j++) {
-        const uint32_t *tj = tf + (size_t)j * 8;
-        uint32_t d = 0;
+        for (int j = ja; j < jb; j++) {
+            const uint32_t *tj = tf + (size_t)j * 8;
+            uint32_t d = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
-        const uint32_t jl = (uint32_t)(j - t0);
-        uint32_t key = (d << 16) | jl;
-        key = jl == skip ? 0xFFFFFFFFu : key;
-        k2 = min(k2, max(k1, key));
-        k1 = min(k1, key);
+            for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
+            const uint32_t jl = (uint32_t)(j - t0);
+            uint32_t key = (d << 16) | jl;
+            if (check_self) key = jl == skip ? 0xFFFFFFFFu : key;
+            k2 = min(k2, max(k1, key));
+            k1 = min(k1, key);
+        }
+    };
+    if (excl) {
+        const int q0 = blockIdx.x * 64; /* this wave's queries are q0 .. q0+63 */
+        const int sa = imin(imax(q0, t0), t1), sb = imin(imax(q0 + 64, t0), t1);
+        scan(t0, sa, false);
+        scan(sa, sb, true);
+        scan(sb, t1, false);
+    } else {
+        scan(t0, t1, false);
     }
     int d1 = (int)(k1 >> 16), d2 = (int)(k2 >> 16);
     int j1 = d1 == 0xFFFF ? -1 : t0 + (int)(k1 & 0xFFFF);
