@@ -195,6 +195,20 @@ def main():
                 n_l = m["launches"] + s_["launches"]
                 m.update(total_ms=tot, launches=n_l, mean_ms=tot / n_l if n_l else 0.0)
 
+    # The timed region keeps two batches in flight, so a kernel's live duration includes the other
+    # stream's kernels sharing the chip.  A short extra pass on ONE context gives each kernel's
+    # duration when it has the GPU to itself (reported next to the live number, never instead).
+    iso = {}
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(5):
+        ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+        ctx.match_batch_device(0, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+        ctx.synchronize()
+    for s_ in ctx.stats():
+        iso[s_["name"]] = s_["mean_ms"]
+    ctx.profile(False)
+
     # parity spot-check of the measured configuration against the oracle outputs of the baseline leg
     parity = None
     if cpu_outs:
@@ -218,9 +232,12 @@ def main():
         if s["launches"] == 0:
             continue
         gbs = s["algorithmic_bytes"] / (s["mean_ms"] * 1e-3) / 1e9 if s["mean_ms"] > 0 and s["algorithmic_bytes"] else None
+        im = iso.get(s["name"])
         kernels.append({"name": s["name"], "launches_per_step": s["launches"] / a.steps, "mean_ms": round(s["mean_ms"], 5),
                         "total_ms": round(s["total_ms"], 3), "algorithmic_bytes_per_launch": s["algorithmic_bytes"],
-                        "achieved_GBps": None if gbs is None else round(gbs, 1)})
+                        "achieved_GBps": None if gbs is None else round(gbs, 1),
+                        "isolated_mean_ms": None if not im else round(im, 5),
+                        "isolated_GBps": None if not im or not s["algorithmic_bytes"] else round(s["algorithmic_bytes"] / (im * 1e-3) / 1e9, 1)})
     with_bytes = [k for k in kernels if k["achieved_GBps"] is not None]
     dom = max(with_bytes, key=lambda k: k["total_ms"]) if with_bytes else None
     traffic = None
@@ -232,7 +249,12 @@ def main():
     roofline = None
     if dom:
         roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic}
+                    "unit": "GB/s", "frac": round(dom["achieved_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "achieved_isolated": dom["isolated_GBps"],
+                    "frac_isolated": None if not dom["isolated_GBps"] else round(dom["isolated_GBps"] / HBM_PEAK_GBS, 4),
+                    "note": "integer-VALU-bound kernel (DESIGN.md section 5): HBM fraction is reported because the "
+                            "contract asks for it, not because HBM limits it; 'achieved' is live with two batches "
+                            "in flight, 'achieved_isolated' is the same kernel alone on the chip"}
 
     total_frames = B * a.steps * world
     out = {

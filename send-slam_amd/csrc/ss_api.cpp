@@ -537,6 +537,17 @@ int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_t
     if (n_query < 0 || n_train < 0 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
     if (n_query == 0) return SS_OK;
     if (!d_query || (!d_train && n_train > 0) || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    if (n_query <= 8 && n_train >= 65536 && !exclude_self) {
+        /* a handful of queries against a large database: stream the database once (HBM-bound) */
+        int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)SSK_STREAM_PARTIAL_MAX);
+        if (rc != SS_OK) return rc;
+        stage_timer t(c, "match_stream", (int64_t)n_query * 32 + (int64_t)n_train * 32 + (int64_t)n_query * 8);
+        if (ssk_match_stream(c->stream, d_query, d_train, n_query, n_train, th, ratio_num, ratio_den, c->match_partial,
+                             c->match_partial_bytes, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2)) {
+            HIP_TRY(c, hipGetLastError());
+            return SS_OK;
+        }
+    }
     int chunk_len = 4;
     const int n_chunks = ssk_match_chunks(n_query, std::max(n_train, 1), 1, &chunk_len);
     if (n_chunks > 1) {

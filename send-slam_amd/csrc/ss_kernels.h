@@ -38,5 +38,9 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
                int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
                int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames);
 #define SSK_MATCH_PARTIAL_BYTES 8
+/* database-streaming form for n_query <= 8 and n_train >= 65536; false = not applicable */
+bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,
+                      void *partial, size_t partial_bytes, int32_t *idx, uint16_t *d1, uint16_t *d2);
+#define SSK_STREAM_PARTIAL_MAX (2048 * 8 * SSK_MATCH_PARTIAL_BYTES)
 
 #endif

@@ -1302,6 +1302,132 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
     d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
 }
 
+/* Same fold for MANY chunks (large databases): one wave per query, lanes stride over the chunks,
+ * then a cross-lane fold on the 64-bit key (distance, global row) -- a lower row wins a tie, the
+ * second best is the smallest of all second distances and the losing first distances. */
+__global__ __launch_bounds__(64) void k_match_merge_wide(const match_partial *__restrict__ partial, int nq, int n_chunks, int th,
+                                                         int rnum, int rden, int out_stride, int32_t *__restrict__ idx_out,
+                                                         uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+{
+    const int qi = blockIdx.x, lane = lane_id();
+    uint64_t best = ~0ull;
+    uint32_t second = 0xFFFFu;
+    for (int c = lane; c < n_chunks; c += WAVE) {
+        const match_partial mp = partial[(size_t)c * out_stride + qi];
+        const uint64_t k = mp.j1 < 0 ? ~0ull : ((uint64_t)mp.d1 << 32) | (uint32_t)mp.j1;
+        const uint64_t loser = k < best ? best : k;
+        best = k < best ? k : best;
+        const uint32_t ld = loser == ~0ull ? 0xFFFFu : (uint32_t)(loser >> 32);
+        second = min(min(second, (uint32_t)mp.d2), ld);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t ob = __shfl_xor(best, o, 64);
+        const uint32_t os = (uint32_t)__shfl_xor((int)second, o, 64);
+        const uint64_t loser = ob < best ? best : ob;
+        best = ob < best ? ob : best;
+        const uint32_t ld = loser == ~0ull ? 0xFFFFu : (uint32_t)(loser >> 32);
+        second = min(min(second, os), ld);
+    }
+    if (lane == 0) {
+        const int d1 = best == ~0ull ? 0xFFFF : (int)(best >> 32), d2 = (int)second;
+        const int j1 = best == ~0ull ? -1 : (int)(uint32_t)best;
+        const bool ok = qi < nq && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
+        idx_out[qi] = ok ? j1 : -1;
+        d1_out[qi] = (uint16_t)d1;
+        d2_out[qi] = (uint16_t)d2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K7, database-streaming form (loop closure / relocalisation with a HANDFUL of query         */
+/* descriptors against millions of keyframe descriptors: BASELINE.json config 5 in the regime   */
+/* SURVEY.md section 8(d) calls HBM-bound).  Roles are swapped: a lane owns a TRAIN row (two    */
+/* coalesced 16-B loads per row, the database is read exactly once), the <= 8 queries are       */
+/* wave-uniform and sit in SGPRs.  19 VALU per (query, row): at 8 queries the integer pipe      */
+/* still keeps up with ~5 TB/s of rows.  Each block owns a contiguous chunk so that partials    */
+/* stay ordered by index and the ordinary k_match_merge folds them.                             */
+/* ------------------------------------------------------------------------------------ */
+template <int NQ>
+__global__ __launch_bounds__(256) void k_match_stream(const uint32_t *__restrict__ query, const uint4 *__restrict__ train,
+                                                      int nq, int nt, int chunk_len, int n_chunks,
+                                                      match_partial *__restrict__ partial)
+{
+    __shared__ uint64_t s_k1[4][NQ];
+    __shared__ uint32_t s_d2[4][NQ];
+    const int chunk = blockIdx.x;
+    const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
+    uint32_t k1[NQ], k2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) k1[q] = k2[q] = 0xFFFFFFFFu;
+    /* key = distance << 22 | iteration: per lane, iterations visit ascending rows, so the
+     * smallest key is the lane's best distance at its lowest row */
+    /* two rows per trip: four 16-B loads are in flight before the first XOR needs its operand */
+    auto score_row = [&](const uint4 lo, const uint4 hi, uint32_t it) {
+        const uint32_t tw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t *qp = query + (size_t)imin(q, nq - 1) * 8; /* uniform: scalar loads */
+            uint32_t d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) d += __popc(tw[k] ^ qp[k]);
+            const uint32_t key = (d << 22) | it;
+            k2[q] = min(k2[q], max(k1[q], key));
+            k1[q] = min(k1[q], key);
+        }
+    };
+    uint32_t it = 0;
+    int j = c0 + (int)threadIdx.x;
+    for (; j + 256 < c1; j += 512, it += 2) {
+        const uint4 lo0 = train[(size_t)j * 2], hi0 = train[(size_t)j * 2 + 1];
+        const uint4 lo1 = train[(size_t)(j + 256) * 2], hi1 = train[(size_t)(j + 256) * 2 + 1];
+        score_row(lo0, hi0, it);
+        score_row(lo1, hi1, it + 1);
+    }
+    if (j < c1) score_row(train[(size_t)j * 2], train[(size_t)j * 2 + 1], it);
+    /* fold the 256 lanes: compare (distance, global row) as one 64-bit key; the second best is
+     * the smallest distance among every lane's second key and the losing lanes' first keys */
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t d1 = k1[q] >> 22;
+        const uint32_t row = (uint32_t)c0 + (k1[q] & 0x3FFFFFu) * 256u + threadIdx.x;
+        uint64_t best = k1[q] == 0xFFFFFFFFu ? ~0ull : ((uint64_t)d1 << 32) | row;
+        uint32_t second = k2[q] == 0xFFFFFFFFu ? 0xFFFFu : k2[q] >> 22;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t ob = __shfl_xor(best, o, 64);
+            const uint32_t os = (uint32_t)__shfl_xor((int)second, o, 64);
+            const uint64_t loser = ob < best ? best : ob;
+            best = ob < best ? ob : best;
+            const uint32_t ld = loser == ~0ull ? 0xFFFFu : (uint32_t)(loser >> 32);
+            second = min(min(second, os), ld);
+        }
+        if (lane == 0) {
+            s_k1[wave][q] = best;
+            s_d2[wave][q] = second;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NQ && (int)threadIdx.x < nq) {
+        const int q = threadIdx.x;
+        uint64_t best = s_k1[0][q];
+        uint32_t second = s_d2[0][q];
+        for (int wv = 1; wv < 4; wv++) {
+            const uint64_t ob = s_k1[wv][q];
+            const uint64_t loser = ob < best ? best : ob;
+            best = ob < best ? ob : best;
+            const uint32_t ld = loser == ~0ull ? 0xFFFFu : (uint32_t)(loser >> 32);
+            second = min(min(second, s_d2[wv][q]), ld);
+        }
+        match_partial mp;
+        mp.d1 = best == ~0ull ? (uint16_t)0xFFFF : (uint16_t)(best >> 32);
+        mp.d2 = (uint16_t)second;
+        mp.j1 = best == ~0ull ? -1 : (int32_t)(uint32_t)best;
+        partial[(size_t)chunk * nq + q] = mp;
+    }
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------------------------ */
@@ -1402,9 +1528,35 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
     hipLaunchKernelGGL(k_match, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
                        nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
                        n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
-    if (n_chunks > 1) {
+    if (n_chunks >= 32 && n_frames == 1 && !nq_arr) {
+        hipLaunchKernelGGL(k_match_merge_wide, dim3(out_stride), dim3(64), 0, s, (const match_partial *)partial, nq_fixed, n_chunks,
+                           th, rnum, rden, out_stride, idx, d1, d2);
+    } else if (n_chunks > 1) {
         dim3 g2((out_stride + 255) / 256, n_frames);
         hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, (const match_partial *)partial, nq_arr, nq_fixed,
                            n_chunks, th, rnum, rden, out_stride, idx, d1, d2);
     }
+}
+
+/* database-streaming match for n_query <= 8 (see k_match_stream); returns false if not applicable */
+bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,
+                      void *partial, size_t partial_bytes, int32_t *idx, uint16_t *d1, uint16_t *d2)
+{
+    if (nq < 1 || nq > 8 || nt < 65536) return false;
+    int n_chunks = 256 * 8;                       /* 8 resident blocks per CU */
+    int chunk_len = (nt + n_chunks - 1) / n_chunks;
+    chunk_len = (chunk_len + 255) & ~255;          /* whole iterations of the block */
+    if (chunk_len > (1 << 22) * 256 / 256) return false;
+    n_chunks = (nt + chunk_len - 1) / chunk_len;
+    if ((size_t)n_chunks * nq * SSK_MATCH_PARTIAL_BYTES > partial_bytes) return false;
+    const uint32_t *q = (const uint32_t *)query;
+    const uint4 *t = (const uint4 *)train;
+    match_partial *p = (match_partial *)partial;
+    if (nq == 1) hipLaunchKernelGGL(k_match_stream<1>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
+    else if (nq == 2) hipLaunchKernelGGL(k_match_stream<2>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
+    else if (nq <= 4) hipLaunchKernelGGL(k_match_stream<4>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
+    else hipLaunchKernelGGL(k_match_stream<8>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
+    hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
+                       idx, d1, d2);
+    return true;
 }

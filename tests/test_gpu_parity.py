@@ -239,3 +239,29 @@ def test_full_size_properties_metric_config():
         # matching a set against itself WITHOUT exclusion is the identity at distance 0
         idx0, z1, _ = ctx.match(d1, d1, th=256, ratio_num=10)
         assert (z1 == 0).all()
+
+
+@pytest.mark.parametrize("nq", [1, 2, 3, 5, 8])
+def test_match_database_streaming_form(oracle, nq):
+    """n_query <= 8 against a large database takes the lane-per-train streaming kernel (config 5 in
+    its HBM-bound regime); results must equal the oracle's, ties across block chunks included."""
+    rng = np.random.default_rng(500 + nq)
+    nt = 200003
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    t[77] = q[0]
+    t[150000] = q[0]             # same best twice, far apart: lowest row wins, d2 == d1 == 0
+    t[199999] = q[nq - 1]
+    t[199999, 9] ^= 0x81         # distance 2 at the very end of the last chunk
+    t[5] = q[nq - 1]
+    t[5, 0] ^= 0x07              # distance 3 near the start: second best
+    with binding.OrbContext(0) as ctx:
+        for kw in (dict(th=50, ratio_num=9), dict(th=256, ratio_num=10), dict(th=-1, ratio_num=9)):
+            got = ctx.match(q, t, ratio_den=10, **kw)
+            want = oracle.match(q, t, ratio_den=10, **kw)
+            for a, b, name in zip(got, want, ("idx", "d1", "d2")):
+                assert np.array_equal(a, b), f"{name} differs ({kw})"
+        names = [s_["name"] for s_ in ctx.stats()]
+    raw = oracle.match(q, t, th=-1)
+    assert raw[0][0] == 77 and raw[1][0] == 0 and raw[2][0] == 0
+    assert raw[0][nq - 1] == (77 if nq == 1 else 199999)
