@@ -43,8 +43,6 @@ template <typename T> void dev_free(T *&p)
 struct ss_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr; /* blur runs beside the FAST -> quadtree chain */
-    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
     ss_orb_params params{};
     std::string err;
     bool calibrated = false;
@@ -275,8 +273,10 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
     }
     {
-        stage_timer t(c, "fast_score", n * all_px);
-        ssk_fast_score(s, c->pyr, c->score, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, n);
+        /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map is this
+         * design's own intermediate) */
+        stage_timer t(c, "fast_blur", n * 2 * all_px);
+        ssk_fast_blur(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, n);
     }
     HIP_TRY(c, hipMemsetAsync(c->cell_cnt, 0, (size_t)n * g.n_cells * sizeof(uint32_t), s));
     {
@@ -287,16 +287,6 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         stage_timer t(c, "cells_emit", n * all_px);
         ssk_cells_emit(s, c->score, c->flags, c->dg, g, c->cell_cnt, c->cand, c->state, n);
     }
-    /* The blurred pyramid is only needed by the descriptor stage: it runs on a second stream
-     * beside the quadtree (one wave per tree: latency-bound, most CUs idle) and joins before
-     * orient_describe. */
-    HIP_TRY(c, hipEventRecord(c->ev_pyr, s));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_pyr, 0));
-    {
-        stage_timer t(c, "blur", n * 2 * all_px, c->stream2);
-        ssk_blur(c->stream2, c->pyr, c->blur, c->dg, g, c->d_tiles2, n);
-    }
-    HIP_TRY(c, hipEventRecord(c->ev_blur, c->stream2));
     {
         stage_timer t(c, "quadtree", 0);
         ssk_quadtree(s, c->dg, g, c->cand, c->qbuf0, c->qbuf1, c->nodes, c->lists, c->sel, c->state, n);
@@ -305,7 +295,6 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         stage_timer t(c, "slots", 0);
         ssk_slots(s, c->dg, c->sel, c->state, c->kp_ref, c->n_kp, c->level_counts, c->frame_error, n);
     }
-    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     {
         stage_timer t(c, "orient_describe", (int64_t)n * g.n_features * (709 + 512 + 32 + 24));
         ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n);
@@ -388,9 +377,6 @@ int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
     c->device = device_ordinal;
     c->params = p;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming);
-    if (se == hipSuccess) se = hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming);
     if (se != hipSuccess) {
         delete c;
         return fail(nullptr, SS_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(se));
@@ -412,9 +398,6 @@ int ss_destroy(ss_ctx *c)
     dev_free(c->d_mq);
     dev_free(c->d_mt);
     dev_free(c->d_mout);
-    if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
-    if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SS_OK;

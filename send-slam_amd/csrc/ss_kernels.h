@@ -12,10 +12,9 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
                 int level, int n_frames);
-void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames);
-void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-              const uint32_t *tiles, int n_frames);
+/* K2 + K6a fused: FAST response map, per-tile corner lists and the blurred pyramid from one staged tile */
+void ssk_fast_blur(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+                   const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames);
 void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
              const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
              uint32_t *cell_cnt, int n_frames);

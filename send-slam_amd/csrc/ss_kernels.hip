@@ -6,14 +6,14 @@
  * /root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc:594:
  *   K0  k_ingest        cvtColor RGB/BGR -> gray (or pitched copy) into pyramid level 0
  *   K1  k_resize        ORBextractor::ComputePyramid: cv::resize INTER_LINEAR, level by level
- *   K2  k_fast_score    cv::FAST-9-16 corner response R-1 for every pixel (threshold-free)
+ *   K2 + K6a k_fast_score  cv::FAST-9-16 corner response R-1 for every pixel (threshold-free) and,
+ *                       from the same staged tile, GaussianBlur 7x7 sigma 2 (8-bit fixed-point path)
  *   K3  k_nms, k_cells_emit   35-px cell grid: NMS inside each cell window (sparse, on the corner
  *                       list FAST leaves; atomics for per-cell counts), iniTh -> minTh fallback, ordered
  *                       compaction into the candidate list (one wave per cell)
  *   K4  k_quadtree      ORBextractor::DistributeOctTree, one wave per (frame, level)
  *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
- *   K6a k_blur          GaussianBlur 7x7 sigma 2, 8-bit fixed-point path
  *   K7  k_match / k_match_merge   Hamming best / second best + ratio test
  *
  * Integer / byte work throughout: no MFMA (nothing here is a dense contraction).  Every
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 /* min(v - p) and of min(p - v); a pixel is a corner at threshold t iff R > t and its      */
 /* cv::cornerScore is R - 1 for every such t, so ONE map serves iniTh and minTh.  Stored:  */
 /* R - 1 if R > minTh else 0.  64x32 tile per 256-thread block; the tile plus its 3-px    */
-/* ring halo is staged in LDS as aligned dwords.                        */
+/* ring halo is staged in LDS as aligned dwords.  The 7x7 Gaussian (K6a) needs exactly the same  */
+/* tile and halo, so it rides in the same kernel: one global read feeds both.                        */
 /* ------------------------------------------------------------------------------------ */
 #define FT_ROWS (SS_TILE_H2 + 6)
 #define FT_WORDS (SS_TILE_W / 4 + 2)
@@ -197,13 +198,32 @@ __device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k com
     return (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
 }
 
+__device__ __forceinline__ int reflect101(int p, int n)
+{
+    if (p < 0) p = -p;
+    if (p >= n) p = 2 * n - 2 - p;
+    return p < 0 ? 0 : (p >= n ? n - 1 : p);
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
+
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr,
                                                     uint8_t *__restrict__ score,
                                                     const ss_geom *__restrict__ g,
                                                     const uint32_t *__restrict__ tiles,
                                                     uint16_t *__restrict__ corner_list,
-                                                    uint16_t *__restrict__ corner_cnt)
+                                                    uint16_t *__restrict__ corner_cnt,
+                                                    uint8_t *__restrict__ blur)
 {
+    /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
+     * so the vertical pass is four v_dot2_u32_u16 per output */
+    __shared__ uint32_t hpair[FT_ROWS / 2][SS_TILE_W];
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
     __shared__ uint32_t out_tile[SS_TILE_H2][SS_TILE_W / 4];
     __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2];
@@ -220,19 +240,29 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
-     * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2 */
+     * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
+     * the image are filled by BORDER_REFLECT_101 (what the blur needs; FAST never evaluates a
+     * pixel whose ring leaves the image, so it does not care). */
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
         const int r = ty + 16 * rr;
         if (r < FT_ROWS) {
             const int gy = y0 - 3 + r;
-            const bool row_ok = gy >= 0 && gy < h;
-            const uint8_t *row = img + (size_t)gy * pitch;
-            const int gx = x0 - 4 + 4 * tx;
-            lds[r][tx] = (row_ok && gx >= 0 && gx < pitch) ? *(const uint32_t *)(row + gx) : 0u;
-            if (tx < 2) {
-                const int gx2 = x0 + 60 + 4 * tx;
-                lds[r][16 + tx] = (row_ok && gx2 < pitch) ? *(const uint32_t *)(row + gx2) : 0u;
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                if (cc == 1 && tx >= 2) break;
+                const int c = cc == 0 ? tx : 16 + tx;
+                const int gx = x0 - 4 + 4 * c;
+                uint32_t v;
+                if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
+                    v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
+                } else {
+                    const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
+                    v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+                }
+                lds[r][c] = v;
             }
         }
     }
@@ -276,6 +306,25 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             }
         }
     }
+    /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
+     * window [x-3, x+4] */
+    {
+        constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
+        constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
+        uint16_t *h16 = (uint16_t *)&hpair[0][0];
+        for (int idx = threadIdx.x; idx < FT_ROWS * 16; idx += 256) {
+            const int r = idx >> 4, q = idx & 15;
+            const uint32_t w0 = lds[r][q], w1 = lds[r][q + 1], w2 = lds[r][q + 2];
+            uint32_t hv[4];
+            hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
+            hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
+            hv[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
+            hv[3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
+            uint16_t *dst = h16 + ((size_t)(r >> 1) * SS_TILE_W + 4 * q) * 2 + (r & 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) dst[2 * i] = (uint16_t)hv[i];
+        }
+    }
     __syncthreads();
 
     /* Phase 2, queued pixels only: R = max over the 16 arcs of min9(v - p) and of min9(p - v) */
@@ -311,6 +360,29 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             corners[atomicAdd(&n_corner, 1)] = list[e];
         }
     }
+    /* K6a vertical pass, two output rows per thread (rows 2ty and 2ty+1 read the same four row
+     * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path */
+    {
+        constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
+        constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
+        constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
+        constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
+        uint32_t out_a = 0, out_b = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
+            const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
+            const uint32_t a = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
+            const uint32_t b = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
+            out_a |= ((a >> 16) & 0xFFu) << (8 * i);
+            out_b |= ((b >> 16) & 0xFFu) << (8 * i);
+        }
+        const int ya = y0 + 2 * ty;
+        if (x0 + 4 * tx < pitch) {
+            if (ya < h) *(uint32_t *)(blur + fb + (size_t)ya * pitch + x0 + 4 * tx) = out_a;
+            if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
@@ -325,107 +397,6 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
     for (int e = threadIdx.x; e < nc; e += 256) cl[e] = corners[e];
     if (threadIdx.x == 0) corner_cnt[slot] = (uint16_t)nc;
-}
-
-/* ------------------------------------------------------------------------------------ */
-/* K6a: 7x7 sigma-2 Gaussian, OpenCV 8U fixed-point path: horizontal taps in 8 fractional */
-/* bits to u16, vertical taps to 16 fractional bits, + 2^15 >> 16.  BORDER_REFLECT_101 is   */
-/* applied while staging the tile (no stored border).                                     */
-/* ------------------------------------------------------------------------------------ */
-__device__ __forceinline__ int reflect101(int p, int n)
-{
-    if (p < 0) p = -p;
-    if (p >= n) p = 2 * n - 2 - p;
-    return p < 0 ? 0 : (p >= n ? n - 1 : p);
-}
-
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
-{
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
-}
-
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              const ss_geom *__restrict__ g,
-                                              const uint32_t *__restrict__ tiles)
-{
-    __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
-    /* horizontal sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel so the
-     * vertical pass is four v_dot2_u32_u16 per output */
-    __shared__ uint32_t hpair[FT_ROWS / 2][SS_TILE_W];
-    const uint32_t t = tiles[xcd_remap((int)blockIdx.x, (int)gridDim.x)];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
-    const ss_level &L = g->lv[level];
-    const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
-    const uint8_t *img = pyr + fb;
-    const int w = L.w, h = L.h, pitch = L.pitch;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-
-    /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67, BORDER_REFLECT_101 applied here */
-#pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-        const int r = ty + 16 * rr;
-        if (r < FT_ROWS) {
-            const int gy = y0 - 3 + r;
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                const int c = cc == 0 ? tx : 16 + tx;
-                if (cc == 1 && tx >= 2) break;
-                const int gx = x0 - 4 + 4 * c;
-                uint32_t v;
-                if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
-                    v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
-                } else {
-                    const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
-                    v = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
-                }
-                lds[r][c] = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    /* horizontal pass: 7 taps = two v_dot4_u32_u8 on the byte window [x-3, x+4] */
-    constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
-    constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
-    uint16_t *h16 = (uint16_t *)&hpair[0][0];
-    for (int idx = threadIdx.x; idx < FT_ROWS * 16; idx += 256) {
-        const int r = idx >> 4, q = idx & 15;
-        const uint32_t w0 = lds[r][q], w1 = lds[r][q + 1], w2 = lds[r][q + 2];
-        uint32_t hv[4];
-        hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
-        hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
-        hv[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
-        hv[3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
-        uint16_t *dst = h16 + ((size_t)(r >> 1) * SS_TILE_W + 4 * q) * 2 + (r & 1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) dst[2 * i] = (uint16_t)hv[i];
-    }
-    __syncthreads();
-
-    /* vertical pass, two output rows per thread: rows 2ty and 2ty+1 read the same four row pairs */
-    constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
-    constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
-    constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
-    constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
-    uint32_t out_a = 0, out_b = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
-        const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
-        const uint32_t a = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
-        const uint32_t b = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
-        out_a |= ((a >> 16) & 0xFFu) << (8 * i);
-        out_b |= ((b >> 16) & 0xFFu) << (8 * i);
-    }
-    const int ya = y0 + 2 * ty;
-    if (x0 + 4 * tx < pitch) {
-        if (ya < h) *(uint32_t *)(blur + fb + (size_t)ya * pitch + x0 + 4 * tx) = out_a;
-        if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
-    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1224,33 +1195,21 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     const int t0 = imin(c0 + wave * quarter, c1), t1 = imin(t0 + quarter, c1);
 
     uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    /* 16 VALU per pair for the distance (XOR + popcount-accumulate with SGPR operands) + 4 to
-     * keep the two smallest keys.  Only the <= 64 train rows whose index equals one of this
-     * wave's query indices can be a self pair: the loop is split so the other rows skip the
-     * j == i test.  Unrolled by 4 so several s_load_dwordx8 are in flight. */
-    auto scan = [&](int ja, int jb, bool check_self) {
-        const uint32_t skip = (uint32_t)(qi - t0);
+    /* 16 VALU per pair for the distance (XOR + popcount-accumulate with SGPR operands) + 6 to
+     * form the key, mask the self pair and keep the two smallest keys.  Unrolled by 4 so several
+     * s_load_dwordx8 are in flight before the first XOR needs its operand. */
+    const uint32_t skip = excl ? (uint32_t)(qi - t0) : 0xFFFFFFFFu; /* local index this lane must skip */
 #pragma unroll 4
-        for (int j = ja; j < jb; j++) {
-            const uint32_t *tj = tf + (size_t)j * 8;
-            uint32_t d = 0;
+    for (int j = t0; j < t1; j++) {
+        const uint32_t *tj = tf + (size_t)j * 8;
+        uint32_t d = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
-            const uint32_t jl = (uint32_t)(j - t0);
-            uint32_t key = (d << 16) | jl;
-            if (check_self) key = jl == skip ? 0xFFFFFFFFu : key;
-            k2 = min(k2, max(k1, key));
-            k1 = min(k1, key);
-        }
-    };
-    if (excl) {
-        const int q0 = blockIdx.x * 64; /* this wave's queries are q0 .. q0+63 */
-        const int sa = imin(imax(q0, t0), t1), sb = imin(imax(q0 + 64, t0), t1);
-        scan(t0, sa, false);
-        scan(sa, sb, true);
-        scan(sb, t1, false);
-    } else {
-        scan(t0, t1, false);
+        for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
+        const uint32_t jl = (uint32_t)(j - t0);
+        uint32_t key = (d << 16) | jl;
+        key = jl == skip ? 0xFFFFFFFFu : key;
+        k2 = min(k2, max(k1, key));
+        k1 = min(k1, key);
     }
     int d1 = (int)(k1 >> 16), d2 = (int)(k2 >> 16);
     int j1 = d1 == 0xFFFF ? -1 : t0 + (int)(k1 & 0xFFFF);
@@ -1455,16 +1414,11 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
     }
 }
 
-void ssk_fast_score(hipStream_t s, const uint8_t *pyr, uint8_t *score, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames)
+void ssk_fast_blur(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+                   const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt);
-}
-
-void ssk_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-              const uint32_t *tiles, int n_frames)
-{
-    hipLaunchKernelGGL(k_blur, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, blur, dg, tiles);
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt,
+                       blur);
 }
 
 void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
