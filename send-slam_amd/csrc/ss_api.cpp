@@ -203,8 +203,8 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     int rc = ss_build_geometry(c->params, w, h, &g, &c->tabs, &msg);
     if (rc != SS_OK) return fail(c, rc, msg);
     for (int l = 0; l < g.n_levels; l++)
-        if (g.lv[l].item_cap > 4096)
-            return fail(c, SS_ERR_INVALID_ARG, "n_features too large: per-level quota exceeds 4080");
+        if (g.lv[l].item_cap > 2048)
+            return fail(c, SS_ERR_INVALID_ARG, "n_features too large: per-level quota exceeds 2032");
     c->hg = g;
     const size_t B = (size_t)c->params.max_batch;
     HIP_TRY(c, hipMalloc((void **)&c->dg, sizeof(ss_geom)));

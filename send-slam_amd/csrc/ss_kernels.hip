@@ -545,11 +545,12 @@ __global__ __launch_bounds__(64) void k_cells_emit(const uint8_t *__restrict__ s
 /* K4: DistributeOctTree, array form (DESIGN.md "quadtree"): std::list with push_front /   */
 /* erase == append-only node table whose list order is DESCENDING creation index; every    */
 /* node owns a contiguous, order-preserving segment of a record array (ping-pong buffers), */
-/* so DivideNode is a stable 4-way partition done with ballots.  One wave per tree.        */
+/* so DivideNode is a stable 4-way partition done with ballots.  One 4-wave workgroup per   */
+/* tree: the waves divide four nodes of a pass at once.                                     */
 /* std::sort(compareNodes) is libstdc++ introsort restated on lane 0 (equal keys must come */
 /* out in libstdc++'s order; tests pin the restatement against the real std::sort).        */
 /* ------------------------------------------------------------------------------------ */
-#define QT_MAX_ITEMS 4096
+#define QT_MAX_ITEMS 2048
 
 /* sort item: size[63:32] | UL.x[31:20] | node index[19:0]; compareNodes looks at (size, UL.x) only */
 __device__ __forceinline__ bool item_less(uint64_t a, uint64_t b) { return (a >> 20) < (b >> 20); }
@@ -713,51 +714,68 @@ __device__ __forceinline__ ss_qnode *qt_node(const qt_ctx &q, int idx)
     return idx < QT_LDS_NODES ? q.lds_nodes + idx : q.nodes + idx;
 }
 
-/* ExtractorNode::DivideNode on node idx.  Returns the number of children made; their node
- * indices are n_nodes_before .. n_nodes_before + made - 1 in n1..n4 order. */
-__device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by creation order */)
+/* ExtractorNode::DivideNode is done in two steps so that the four waves of the workgroup can
+ * divide four nodes of a pass at once and still number the children exactly as the sequential
+ * algorithm does: (1) qt_count: quadrant populations of one node, by one wave; (2) after the
+ * workgroup has exchanged the populations and every wave knows where its children go,
+ * qt_scatter: the stable 4-way partition of the node's record segment (ballot + prefix between
+ * the ping-pong buffers) and the child node records. */
+struct qt_div {
+    int x0, x1, y0, y1, xm, ym, beg, cnt, b, flags;
+    uint32_t rec0; /* first 64 records stay in registers between the two steps */
+    int q0;
+};
+
+__device__ __forceinline__ void qt_count(const qt_ctx &q, int idx, qt_div &d, int c[4])
 {
     const ss_qnode nd = *qt_node(q, idx);
-    const int x0 = rfl(nd.x0), x1 = rfl(nd.x1), y0 = rfl(nd.y0), y1 = rfl(nd.y1);
-    const int beg = rfl(nd.beg), cnt = rfl(nd.cnt), b = (rfl(nd.flags) >> 2) & 1;
-    const int xm = x0 + ((x1 - x0 + 1) >> 1); /* ceil((float)(UR.x-UL.x)/2) */
-    const int ym = y0 + ((y1 - y0 + 1) >> 1);
-    const uint32_t *src = q.buf[b] + beg;
-    uint32_t *dst = q.buf[b ^ 1] + beg;
+    d.x0 = rfl(nd.x0); d.x1 = rfl(nd.x1); d.y0 = rfl(nd.y0); d.y1 = rfl(nd.y1);
+    d.beg = rfl(nd.beg); d.cnt = rfl(nd.cnt); d.flags = rfl(nd.flags);
+    d.b = (d.flags >> 2) & 1;
+    d.xm = d.x0 + ((d.x1 - d.x0 + 1) >> 1); /* ceil((float)(UR.x-UL.x)/2) */
+    d.ym = d.y0 + ((d.y1 - d.y0 + 1) >> 1);
+    const uint32_t *src = q.buf[d.b] + d.beg;
     const int lane = lane_id();
-    const uint64_t lt = lanemask_lt();
-
-    int c[4] = {0, 0, 0, 0};
-    uint32_t rec0 = 0;
-    int q0 = 4;
-    for (int base = 0; base < cnt; base += WAVE) {
+    c[0] = c[1] = c[2] = c[3] = 0;
+    d.rec0 = 0;
+    d.q0 = 4;
+    for (int base = 0; base < d.cnt; base += WAVE) {
         const int i = base + lane;
         uint32_t rec = 0;
         int quad = 4;
-        if (i < cnt) {
+        if (i < d.cnt) {
             rec = src[i];
-            quad = (SS_PX(rec) >= xm ? 1 : 0) | (SS_PY(rec) >= ym ? 2 : 0);
+            quad = (SS_PX(rec) >= d.xm ? 1 : 0) | (SS_PY(rec) >= d.ym ? 2 : 0);
         }
-        if (base == 0) { rec0 = rec; q0 = quad; }
+        if (base == 0) { d.rec0 = rec; d.q0 = quad; }
 #pragma unroll
         for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(quad == k));
     }
+}
+
+/* children get node indices first_child, first_child+1, ... in n1..n4 order (empty ones skipped) */
+__device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_div &d, const int c[4], int first_child)
+{
+    const uint32_t *src = q.buf[d.b] + d.beg;
+    uint32_t *dst = q.buf[d.b ^ 1] + d.beg;
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
     int run[4];
     run[0] = 0;
     run[1] = c[0];
     run[2] = c[0] + c[1];
     run[3] = c[0] + c[1] + c[2];
     const int o[4] = {run[0], run[1], run[2], run[3]};
-    for (int base = 0; base < cnt; base += WAVE) {
+    for (int base = 0; base < d.cnt; base += WAVE) {
         const int i = base + lane;
-        uint32_t rec = rec0;
-        int quad = q0;
+        uint32_t rec = d.rec0;
+        int quad = d.q0;
         if (base != 0) {
             rec = 0;
             quad = 4;
-            if (i < cnt) {
+            if (i < d.cnt) {
                 rec = src[i];
-                quad = (SS_PX(rec) >= xm ? 1 : 0) | (SS_PY(rec) >= ym ? 2 : 0);
+                quad = (SS_PX(rec) >= d.xm ? 1 : 0) | (SS_PY(rec) >= d.ym ? 2 : 0);
             }
         }
 #pragma unroll
@@ -767,14 +785,8 @@ __device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by crea
             run[k] += __popcll(m);
         }
     }
-    wave_sync();
-
-    if (q.n_nodes + 4 > q.node_cap) {
-        q.error = -5;
-        return 0;
-    }
-    const int rx0[4] = {x0, xm, x0, xm}, rx1[4] = {xm, x1, xm, x1};
-    const int ry0[4] = {y0, y0, ym, ym}, ry1[4] = {ym, ym, y1, y1};
+    const int rx0[4] = {d.x0, d.xm, d.x0, d.xm}, rx1[4] = {d.xm, d.x1, d.xm, d.x1};
+    const int ry0[4] = {d.y0, d.y0, d.ym, d.ym}, ry1[4] = {d.ym, d.ym, d.y1, d.y1};
     int made = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -784,37 +796,36 @@ __device__ int qt_split(qt_ctx &q, int idx, int *child_cnt /* [4] counts by crea
             ch.x1 = (uint16_t)rx1[k];
             ch.y0 = (uint16_t)ry0[k];
             ch.y1 = (uint16_t)ry1[k];
-            ch.beg = beg + o[k];
+            ch.beg = d.beg + o[k];
             ch.cnt = c[k];
-            ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((b ^ 1) << 2);
-            if (lane == 0) *qt_node(q, q.n_nodes) = ch;
-            child_cnt[made] = c[k];
-            q.n_nodes++;
-            q.size++;
+            ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((d.b ^ 1) << 2);
+            if (lane == 0) *qt_node(q, first_child + made) = ch;
             made++;
         }
     }
-    if (lane == 0) qt_node(q, idx)->flags = nd.flags & ~1; /* lNodes.erase */
-    q.size--;
-    wave_sync();
-    return made;
+    if (lane == 0) qt_node(q, idx)->flags = d.flags & ~1; /* lNodes.erase */
 }
 
-__global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
-                                                 uint32_t *__restrict__ qbuf0, uint32_t *__restrict__ qbuf1,
-                                                 ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
-                                                 uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
+#define QT_WAVES 4
+
+__global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
+                                                  uint32_t *__restrict__ qbuf0, uint32_t *__restrict__ qbuf1,
+                                                  ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
+                                                  uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
 {
     __shared__ uint64_t items[QT_MAX_ITEMS];
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
+    __shared__ int grp_cnt[QT_WAVES][4];
+    __shared__ int wave_alive[QT_WAVES];
     const int level = blockIdx.x, frame = blockIdx.y;
     const ss_level &L = g->lv[level];
     ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
     const int lane = lane_id();
+    const int wave = rfl((int)(threadIdx.x >> 6));
     const uint64_t lt = lanemask_lt();
     const int n_cand = rfl(st->n_cand);
     if (rfl(st->error) != 0 || n_cand == 0) {
-        if (lane == 0) st->n_sel = 0;
+        if (threadIdx.x == 0) st->n_sel = 0;
         return;
     }
     const int N = L.quota;
@@ -834,75 +845,136 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
     const int list_cap = L.item_cap;
 
     /* roots: vpIniNodes[kp.pt.x / hX]; list order r0, r1, ... == descending creation index,
-     * so root i gets node index n_ini-1-i.  Stable partition of the candidates by root. */
+     * so root i gets node index n_ini-1-i.  Stable partition of the candidates by root (wave 0). */
     const int n_ini = L.n_ini;
-    const float hx = L.hx;
-    const int height = (L.h - SS_EDGE_THRESHOLD + 3) - SS_MIN_BORDER;
-    int root_beg = 0;
-    for (int r = 0; r < n_ini; r++) {
-        int cnt_r = 0;
-        for (int base = 0; base < n_cand; base += WAVE) {
-            const int i = base + lane;
-            bool mine = false;
-            uint32_t rec = 0;
-            if (i < n_cand) {
-                rec = in[i];
-                mine = (int)((float)SS_PX(rec) / hx) == r;
+    if (wave == 0) {
+        const float hx = L.hx;
+        const int height = (L.h - SS_EDGE_THRESHOLD + 3) - SS_MIN_BORDER;
+        int root_beg = 0;
+        for (int r = 0; r < n_ini; r++) {
+            int cnt_r = 0;
+            for (int base = 0; base < n_cand; base += WAVE) {
+                const int i = base + lane;
+                bool mine = false;
+                uint32_t rec = 0;
+                if (i < n_cand) {
+                    rec = in[i];
+                    mine = (int)((float)SS_PX(rec) / hx) == r;
+                }
+                const uint64_t m = __ballot(mine);
+                if (mine) q.buf[0][root_beg + cnt_r + __popcll(m & lt)] = rec;
+                cnt_r += __popcll(m);
             }
-            const uint64_t m = __ballot(mine);
-            if (mine) q.buf[0][root_beg + cnt_r + __popcll(m & lt)] = rec;
-            cnt_r += __popcll(m);
+            ss_qnode nd;
+            nd.x0 = (uint16_t)(int)(hx * (float)r);
+            nd.x1 = (uint16_t)(int)(hx * (float)(r + 1));
+            nd.y0 = 0;
+            nd.y1 = (uint16_t)height;
+            nd.beg = root_beg;
+            nd.cnt = cnt_r;
+            nd.flags = (cnt_r > 0 ? 1 : 0) | (cnt_r == 1 ? 2 : 0); /* empty roots are erased */
+            if (lane == 0) *qt_node(q, n_ini - 1 - r) = nd;
+            root_beg += cnt_r;
         }
-        ss_qnode nd;
-        nd.x0 = (uint16_t)(int)(hx * (float)r);
-        nd.x1 = (uint16_t)(int)(hx * (float)(r + 1));
-        nd.y0 = 0;
-        nd.y1 = (uint16_t)height;
-        nd.beg = root_beg;
-        nd.cnt = cnt_r;
-        nd.flags = (cnt_r > 0 ? 1 : 0) | (cnt_r == 1 ? 2 : 0); /* empty roots are erased */
-        if (lane == 0) *qt_node(q, n_ini - 1 - r) = nd;
-        if (cnt_r > 0) q.size++;
-        root_beg += cnt_r;
+        if (lane == 0) grp_cnt[0][0] = root_beg;
     }
+    __syncthreads();
+    if (grp_cnt[0][0] != n_cand) q.error = -5; /* a candidate outside every root: cannot happen */
     q.n_nodes = n_ini;
-    wave_sync();
-    if (root_beg != n_cand) q.error = -5; /* a candidate outside every root: cannot happen */
 
     /* expandable roots in creation order (= root n_ini-1 first) */
     int32_t *cur = list_a, *nxt = list_b;
     int n_cur = 0;
     for (int idx = 0; idx < n_ini; idx++) {
         const int fl = rfl(qt_node(q, idx)->flags);
+        if (fl & 1) q.size++;
         if ((fl & 1) && !(fl & 2)) {
-            if (lane == 0) cur[n_cur] = idx;
+            if (threadIdx.x == 0) cur[n_cur] = idx;
             n_cur++;
         }
     }
-    wave_sync();
+    __syncthreads();
+
+    /* One sweep over a list of nodes to divide, in the given order, four at a time (one per
+     * wave).  `stop_at_n`: the sorted phase, which stops as soon as lNodes.size() >= N.  Returns
+     * through n_nxt the expandable children appended to `nxt`, through n_to_expand their count. */
+    auto sweep = [&](auto node_at, int n_list, bool stop_at_n, int &n_nxt, int &n_to_expand) -> bool {
+        bool stopped = false;
+        for (int k0 = 0; k0 < n_list && !stopped && q.error == 0; k0 += QT_WAVES) {
+            const int k = k0 + wave;
+            const bool have = k < n_list;
+            qt_div d;
+            int c[4] = {0, 0, 0, 0};
+            int idx = -1;
+            if (have) {
+                idx = rfl(node_at(k));
+                qt_count(q, idx, d, c);
+            }
+            if (lane == 0) {
+                grp_cnt[wave][0] = c[0];
+                grp_cnt[wave][1] = c[1];
+                grp_cnt[wave][2] = c[2];
+                grp_cnt[wave][3] = c[3];
+            }
+            __syncthreads();
+            /* every thread replays the sequential bookkeeping of the (up to) four divisions */
+            int my_first_child = 0, my_first_nxt = 0;
+            bool my_go = false;
+            for (int w = 0; w < QT_WAVES && k0 + w < n_list; w++) {
+                int made = 0, expandable = 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    const int cc = grp_cnt[w][qd];
+                    made += cc > 0;
+                    expandable += cc > 1;
+                }
+                if (q.n_nodes + 4 > q.node_cap || n_nxt + expandable > list_cap) {
+                    q.error = -5;
+                    break;
+                }
+                if (w == wave) {
+                    my_go = true;
+                    my_first_child = q.n_nodes;
+                    my_first_nxt = n_nxt;
+                }
+                q.n_nodes += made;
+                q.size += made - 1;
+                n_nxt += expandable;
+                n_to_expand += expandable;
+                if (stop_at_n && q.size >= N) {
+                    stopped = true;
+                    break;
+                }
+            }
+            if (have && my_go && q.error == 0) {
+                qt_scatter(q, idx, d, c, my_first_child);
+                if (lane == 0) {
+                    int child = my_first_child, pos = my_first_nxt;
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++) {
+                        if (c[qd] > 0) {
+                            if (c[qd] > 1) nxt[pos++] = child;
+                            child++;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return stopped;
+    };
 
     bool finish = false;
     while (!finish && q.error == 0) {
         const int prev_size = q.size;
         int n_to_expand = 0, n_nxt = 0;
-        /* one full pass: lit walks the list (descending creation index); every node that
-         * existed at the start and is not final is divided */
-        for (int k = n_cur - 1; k >= 0 && q.error == 0; k--) {
-            const int idx = rfl(cur[k]);
-            int cc[4];
-            const int first_child = q.n_nodes;
-            const int made = qt_split(q, idx, cc);
-            for (int m = 0; m < made; m++)
-                if (cc[m] > 1) {
-                    n_to_expand++;
-                    if (n_nxt < list_cap) {
-                        if (lane == 0) nxt[n_nxt] = first_child + m;
-                    } else
-                        q.error = -5;
-                    n_nxt++;
-                }
+        /* one full pass: lit walks the list (descending creation index); every node that existed
+         * at the start and is not final is divided */
+        {
+            const int32_t *cl = cur;
+            const int nc = n_cur;
+            sweep([&](int k) { return cl[nc - 1 - k]; }, n_cur, false, n_nxt, n_to_expand);
         }
-        wave_sync();
         { int32_t *t = cur; cur = nxt; nxt = t; }
         n_cur = n_nxt;
         if (q.error) break;
@@ -914,33 +986,19 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
                 const int n_prev = n_cur;
                 if (n_prev > QT_MAX_ITEMS) { q.error = -5; break; }
                 /* vPrevSizeAndPointerToNode, in creation order; key = size, then UL.x */
-                for (int j = lane; j < n_prev; j += WAVE) {
+                for (int j = threadIdx.x; j < n_prev; j += 256) {
                     const int idx = cur[j];
                     const ss_qnode nd = *qt_node(q, idx);
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
                 }
-                wave_sync();
-#ifndef SS_QT_NOSORT
-                if (lane == 0) std_sort_items(items, n_prev);
-#endif
-                wave_sync();
+                __syncthreads();
+                if (threadIdx.x == 0) std_sort_items(items, n_prev);
+                __syncthreads();
                 n_nxt = 0;
-                for (int j = n_prev - 1; j >= 0 && q.error == 0; j--) {
-                    const int idx = rfl((int)((uint32_t)items[j] & 0xFFFFFu));
-                    int cc[4];
-                    const int first_child = q.n_nodes;
-                    const int made = qt_split(q, idx, cc);
-                    for (int m = 0; m < made; m++)
-                        if (cc[m] > 1) {
-                            if (n_nxt < list_cap) {
-                                if (lane == 0) nxt[n_nxt] = first_child + m;
-                            } else
-                                q.error = -5;
-                            n_nxt++;
-                        }
-                    if (q.size >= N) break;
-                }
-                wave_sync();
+                int dummy = 0;
+                const bool stopped = sweep([&](int k) { return (int)((uint32_t)items[n_prev - 1 - k] & 0xFFFFFu); }, n_prev, true,
+                                           n_nxt, dummy);
+                (void)stopped;
                 { int32_t *t = cur; cur = nxt; nxt = t; }
                 n_cur = n_nxt;
                 if (q.size >= N || q.size == prev2) finish = true;
@@ -952,32 +1010,36 @@ __global__ __launch_bounds__(64) void k_quadtree(const ss_geom *__restrict__ g, 
     uint32_t *out = sel + (size_t)frame * g->sel_total + L.sel_base;
     int n_out = 0;
     if (q.error == 0) {
-        for (int hi = q.n_nodes - 1; hi >= 0; hi -= WAVE) {
-            const int idx = hi - lane;
+        for (int hi = q.n_nodes - 1; hi >= 0; hi -= 256) {
+            const int idx = hi - (int)threadIdx.x;
             ss_qnode nd;
             nd.flags = 0;
             if (idx >= 0) nd = *qt_node(q, idx);
             const bool alive = idx >= 0 && (nd.flags & 1);
             const uint64_t m = __ballot(alive);
-            const int pos = n_out + __popcll(m & lt);
+            if (lane == 0) wave_alive[wave] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < QT_WAVES; w++) {
+                if (w < wave) before += wave_alive[w];
+                total += wave_alive[w];
+            }
+            const int pos = n_out + before + __popcll(m & lt);
             if (alive && pos < L.sel_cap) {
                 const uint32_t *seg = q.buf[(nd.flags >> 2) & 1] + nd.beg;
                 uint32_t best = seg[0];
-#ifdef SS_QT_NOFINAL
-                for (int k = 1; k < 1; k++) {
-#else
                 for (int k = 1; k < nd.cnt; k++) {
-#endif
                     const uint32_t r = seg[k];
                     if (SS_PR(r) > SS_PR(best)) best = r;
                 }
                 out[pos] = SS_PACK(SS_PX(best) + SS_MIN_BORDER, SS_PY(best) + SS_MIN_BORDER, SS_PR(best));
             }
-            n_out += __popcll(m);
+            n_out += total;
+            __syncthreads();
         }
         if (n_out > L.sel_cap) q.error = -5;
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         st->n_sel = q.error ? 0 : n_out;
         if (q.error) atomicExch(&st->error, q.error);
     }
@@ -1438,7 +1500,7 @@ void ssk_cells_emit(hipStream_t s, const uint8_t *score, const uint8_t *flags, c
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
                   uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_quadtree, dim3(hg.n_levels, n_frames), dim3(64), 0, s, dg, cand, qbuf0, qbuf1, nodes, lists,
+    hipLaunchKernelGGL(k_quadtree, dim3(hg.n_levels, n_frames), dim3(256), 0, s, dg, cand, qbuf0, qbuf1, nodes, lists,
                        sel, state);
 }
 
