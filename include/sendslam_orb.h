@@ -183,6 +183,10 @@ int ss_stats(ss_ctx *ctx, ss_stage_stats *out, int max_stages);
  * relative to the (16,16) border origin, selected are level coordinates).  Returns the
  * number of bytes written to dst (<= dst_bytes) or < 0. */
 int ss_debug_fetch(ss_ctx *ctx, int what, int frame, int level, void *dst, int64_t dst_bytes);
+/* Test hook: sorts n <= 2048 items in place with the device's restatement of libstdc++
+ * std::sort for ORB-SLAM3's compareNodes.  Item = size << 32 | UL.x << 20 | id (20 bits); the
+ * comparator looks at (size, UL.x) only, so the placement of equal keys is what is tested. */
+int ss_debug_sort(ss_ctx *ctx, uint64_t *items, int n);
 
 #ifdef __cplusplus
 }

@@ -696,3 +696,17 @@ int ss_debug_fetch(ss_ctx *c, int what, int frame, int level, void *dst, int64_t
 }
 
 } /* extern "C" */
+
+extern "C" int ss_debug_sort(ss_ctx *c, uint64_t *items, int n)
+{
+    if (!c || (!items && n > 0)) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n == 0) return SS_OK;
+    int rc = grow(c, c->d_mq, c->d_mq_bytes, (size_t)n * 8);
+    if (rc != SS_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_mq, items, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (ssk_debug_sort(c->stream, (uint64_t *)c->d_mq, n) != 0) return fail(c, SS_ERR_INVALID_ARG, "ss_debug_sort: n > 2048");
+    HIP_TRY(c, hipMemcpyAsync(items, c->d_mq, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}

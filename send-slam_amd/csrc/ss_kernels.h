@@ -36,6 +36,8 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
                int nq_fixed, int nt_fixed, int64_t q_frame_stride_words, int64_t t_frame_stride_words,
                int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
                int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames);
+/* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
+int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8
 /* database-streaming form for n_query <= 8 and n_train >= 65536; false = not applicable */
 bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,

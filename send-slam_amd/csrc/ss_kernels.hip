@@ -697,6 +697,141 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+/* The same std::sort, executed by ONE WAVE instead of one lane: identical sequence of element
+ * moves (so identical placement of equal keys), but the two inner scans of the partition and the
+ * shift of the insertion step look at up to 64 elements per LDS round trip (ballot + count
+ * trailing zeros) instead of one.  Control flow is wave-uniform. */
+__device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src_lane)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ void wave_unguarded_linear_insert(uint64_t *a, int last, int lane)
+{
+    const uint64_t val = a[last]; /* uniform address: broadcast read */
+    int pos = last;
+    for (;;) {
+        const int i = pos - 1 - lane;
+        const uint64_t v = a[i < 0 ? 0 : i];
+        const bool shift = i >= 0 && item_less(val, v);
+        const uint64_t m = __ballot(!shift);
+        const int run = m ? (int)__builtin_ctzll(m) : WAVE; /* elements to move right by one */
+        if (lane < run) a[i + 1] = v;
+        pos -= run;
+        if (run < WAVE) break;
+    }
+    wave_sync();
+    if (lane == 0) a[pos] = val;
+    wave_sync();
+}
+
+__device__ void wave_insertion_sort(uint64_t *a, int first, int last, int lane)
+{
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        const uint64_t val = a[i], head = a[first];
+        if (item_less(val, head)) {
+            /* move_backward(first, i, i + 1); *first = val -- at most 16 elements here */
+            for (int top = i; top > first; top -= WAVE) {
+                const int k = top - 1 - lane;
+                uint64_t v = 0;
+                if (k >= first) v = a[k];
+                wave_sync();
+                if (k >= first) a[k + 1] = v;
+                wave_sync();
+            }
+            if (lane == 0) a[first] = val;
+            wave_sync();
+        } else
+            wave_unguarded_linear_insert(a, i, lane);
+    }
+}
+
+/* std::sort(a, a + n, compareNodes) by the 64 lanes of one wave */
+__device__ void std_sort_items_wave(uint64_t *a, int n, int lane)
+{
+    if (n <= 0) return;
+    int lg = 0;
+    for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
+    int stack_first[64], stack_last[64], stack_depth[64];
+    int sp = 1;
+    stack_first[0] = 0;
+    stack_last[0] = n;
+    stack_depth[0] = lg * 2;
+    while (sp > 0) {
+        --sp;
+        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) {
+                wave_sync();
+                if (lane == 0) sort_heap_range(a + first, last - first);
+                wave_sync();
+                break;
+            }
+            --depth;
+            const int mid = first + (last - first) / 2;
+            const int ia = first + 1, ib = mid, ic = last - 1;
+            const uint64_t va = a[ia], vb = a[ib], vc = a[ic];
+            int pick; /* __move_median_to_first */
+            if (item_less(va, vb)) {
+                if (item_less(vb, vc)) pick = ib;
+                else if (item_less(va, vc)) pick = ic;
+                else pick = ia;
+            } else if (item_less(va, vc)) pick = ia;
+            else if (item_less(vb, vc)) pick = ic;
+            else pick = ib;
+            {
+                const uint64_t tf = a[first], tp = a[pick];
+                wave_sync();
+                if (lane == 0) { a[first] = tp; a[pick] = tf; }
+                wave_sync();
+            }
+            const uint64_t pivot = a[first];
+            int lo = first + 1, hi = last; /* __unguarded_partition */
+            for (;;) {
+                uint64_t v_lo, v_hi;
+                for (;;) { /* while (a[lo] < pivot) ++lo; */
+                    const int i = lo + lane;
+                    const uint64_t v = a[i < last ? i : last - 1];
+                    const uint64_t m = __ballot(i >= last || !item_less(v, pivot));
+                    const int adv = m ? (int)__builtin_ctzll(m) : WAVE;
+                    lo += adv;
+                    if (adv < WAVE) { v_lo = lane_bcast64(v, adv); break; }
+                }
+                --hi;
+                for (;;) { /* while (pivot < a[hi]) --hi; */
+                    const int i = hi - lane;
+                    const uint64_t v = a[i > first ? i : first];
+                    const uint64_t m = __ballot(i <= first || !item_less(pivot, v));
+                    const int adv = m ? (int)__builtin_ctzll(m) : WAVE;
+                    hi -= adv;
+                    if (adv < WAVE) { v_hi = lane_bcast64(v, adv); break; }
+                }
+                if (!(lo < hi)) break;
+                wave_sync();
+                if (lane == 0) { a[lo] = v_hi; a[hi] = v_lo; }
+                wave_sync();
+                ++lo;
+            }
+            if (sp < 64) {
+                stack_first[sp] = lo;
+                stack_last[sp] = last;
+                stack_depth[sp] = depth;
+                ++sp;
+            }
+            last = lo;
+        }
+    }
+    wave_sync();
+    if (n > 16) {
+        wave_insertion_sort(a, 0, 16, lane);
+        for (int i = 16; i != n; ++i) wave_unguarded_linear_insert(a, i, lane);
+    } else
+        wave_insertion_sort(a, 0, n, lane);
+}
+
 #define QT_LDS_NODES 1024 /* first nodes of a tree live in LDS, later ones in the global table */
 
 struct qt_ctx {
@@ -992,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g,
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
                 }
                 __syncthreads();
-                if (threadIdx.x == 0) std_sort_items(items, n_prev);
+                if (wave == 0) std_sort_items_wave(items, n_prev, lane);
                 __syncthreads();
                 n_nxt = 0;
                 int dummy = 0;
@@ -1043,6 +1178,18 @@ __global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g,
         st->n_sel = q.error ? 0 : n_out;
         if (q.error) atomicExch(&st->error, q.error);
     }
+}
+
+/* test hook: the device's std::sort restatement on caller data (ss_debug_sort) */
+__global__ __launch_bounds__(64) void k_debug_sort(uint64_t *__restrict__ data, int n)
+{
+    __shared__ uint64_t items[QT_MAX_ITEMS];
+    const int lane = lane_id();
+    for (int i = lane; i < n; i += WAVE) items[i] = data[i];
+    wave_sync();
+    std_sort_items_wave(items, n, lane);
+    wave_sync();
+    for (int i = lane; i < n; i += WAVE) data[i] = items[i];
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1575,4 +1722,11 @@ bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int n
     hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
                        idx, d1, d2);
     return true;
+}
+
+int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n)
+{
+    if (n < 0 || n > QT_MAX_ITEMS) return -1;
+    hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), 0, s, d_items, n);
+    return 0;
 }

@@ -24,7 +24,7 @@ SS_ERR_OVERFLOW, SS_ERR_NOT_CALIBRATED, SS_ERR_BAD_FRAME, SS_ERR_NO_MEMORY, SS_E
 EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy", "ss_last_error",
            "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_fetch_frame", "ss_match",
            "ss_match_device", "ss_match_batch_device", "ss_synchronize", "ss_get_stream",
-           "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch"]
+           "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort"]
 
 
 class OrbParams(C.Structure):
@@ -114,6 +114,7 @@ def load():
     lib.ss_profile_reset.argtypes = [C.c_void_p]
     lib.ss_stats.argtypes = [C.c_void_p, C.POINTER(StageStats), C.c_int]
     lib.ss_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    lib.ss_debug_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     if lib.ss_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI {lib.ss_abi_version()} != {ABI_VERSION}")
     _lib = lib
@@ -257,3 +258,15 @@ class OrbContext:
         out = np.empty(shape, dtype)
         n = self._check(self._lib.ss_debug_fetch(self._h, what, frame, level, out.ctypes.data, out.nbytes))
         return out.reshape(-1)[: n // out.itemsize]
+
+
+def _debug_sort(self, size, ulx):
+    """Permutation (ids) the device's std::sort restatement leaves for compareNodes keys."""
+    n = len(size)
+    items = (np.asarray(size, np.uint64) << np.uint64(32)) | (np.asarray(ulx, np.uint64) << np.uint64(20)) | np.arange(n, dtype=np.uint64)
+    items = np.ascontiguousarray(items)
+    self._check(self._lib.ss_debug_sort(self._h, items.ctypes.data, n))
+    return (items & np.uint64(0xFFFFF)).astype(np.int32)
+
+
+OrbContext.debug_sort = _debug_sort

@@ -226,3 +226,129 @@ def parse_c_int_table(path: str, macro: str):
             end = i
             break
     return [int(v) for v in re.findall(r"-?\d+", body[:end].replace("\\\n", " "))]
+
+
+# ---------------------------------------------------------------------------------------
+# libstdc++ std::sort (introsort) in Python, comparator-driven, used to (a) cross-check the
+# oracle's C restatement once more and (b) run McIlroy's "killer adversary" against it to obtain
+# inputs that reach the depth limit and the heapsort fallback.
+# ---------------------------------------------------------------------------------------
+def std_sort_py(a, less):
+    n = len(a)
+    if n == 0:
+        return a
+
+    def adjust_heap(first, hole, length, value):
+        top, second = hole, hole
+        while second < (length - 1) // 2:
+            second = 2 * (second + 1)
+            if less(a[first + second], a[first + second - 1]):
+                second -= 1
+            a[first + hole] = a[first + second]
+            hole = second
+        if (length & 1) == 0 and second == (length - 2) // 2:
+            second = 2 * (second + 1)
+            a[first + hole] = a[first + second - 1]
+            hole = second - 1
+        parent = (hole - 1) // 2
+        while hole > top and less(a[first + parent], value):
+            a[first + hole] = a[first + parent]
+            hole = parent
+            parent = (hole - 1) // 2
+        a[first + hole] = value
+
+    def heap_sort(first, last):
+        length = last - first
+        if length >= 2:
+            parent = (length - 2) // 2
+            while True:
+                adjust_heap(first, parent, length, a[first + parent])
+                if parent == 0:
+                    break
+                parent -= 1
+        while last - first > 1:
+            last -= 1
+            v = a[last]
+            a[last] = a[first]
+            adjust_heap(first, 0, last - first, v)
+
+    def linear_insert(last):
+        val = a[last]
+        nxt = last - 1
+        while less(val, a[nxt]):
+            a[last] = a[nxt]
+            last = nxt
+            nxt -= 1
+        a[last] = val
+
+    def insertion(first, last):
+        for i in range(first + 1, last):
+            if less(a[i], a[first]):
+                val = a[i]
+                a[first + 1:i + 1] = a[first:i]
+                a[first] = val
+            else:
+                linear_insert(i)
+
+    stack = [(0, n, 2 * (n.bit_length() - 1))]
+    while stack:
+        first, last, depth = stack.pop()
+        while last - first > 16:
+            if depth == 0:
+                heap_sort(first, last)
+                break
+            depth -= 1
+            mid = first + (last - first) // 2
+            ia, ib, ic = first + 1, mid, last - 1
+            if less(a[ia], a[ib]):
+                pick = ib if less(a[ib], a[ic]) else (ic if less(a[ia], a[ic]) else ia)
+            elif less(a[ia], a[ic]):
+                pick = ia
+            elif less(a[ib], a[ic]):
+                pick = ic
+            else:
+                pick = ib
+            a[first], a[pick] = a[pick], a[first]
+            lo, hi = first + 1, last
+            while True:
+                while less(a[lo], a[first]):
+                    lo += 1
+                hi -= 1
+                while less(a[first], a[hi]):
+                    hi -= 1
+                if not lo < hi:
+                    break
+                a[lo], a[hi] = a[hi], a[lo]
+                lo += 1
+            stack.append((lo, last, depth))
+            last = lo
+    if n > 16:
+        insertion(0, 16)
+        for i in range(16, n):
+            linear_insert(i)
+    else:
+        insertion(0, n)
+    return a
+
+
+def quicksort_killer(n):
+    """McIlroy, 'A Killer Adversary for Quicksort': values that drive std_sort_py to its depth limit."""
+    gas = n - 1
+    val = [gas] * n
+    state = {"nsolid": 0, "candidate": 0}
+
+    def less(x, y):
+        if val[x] == gas and val[y] == gas:
+            if x == state["candidate"]:
+                val[x] = state["nsolid"]
+            else:
+                val[y] = state["nsolid"]
+            state["nsolid"] += 1
+        if val[x] == gas:
+            state["candidate"] = x
+        elif val[y] == gas:
+            state["candidate"] = y
+        return val[x] < val[y]
+
+    std_sort_py(list(range(n)), less)
+    return val

@@ -265,3 +265,34 @@ def test_match_database_streaming_form(oracle, nq):
     raw = oracle.match(q, t, th=-1)
     assert raw[0][0] == 77 and raw[1][0] == 0 and raw[2][0] == 0
     assert raw[0][nq - 1] == (77 if nq == 1 else 199999)
+
+
+def test_device_std_sort_restatement_vs_oracle(oracle):
+    """The wave-wide introsort on the device must leave equal keys exactly where libstdc++'s
+    std::sort does (the oracle's restatement is pinned against the real one on the CPU).  Random
+    tie-heavy inputs, sizes around the 16-element threshold, and McIlroy-style adversarial inputs
+    that drive the depth limit into the heapsort fallback."""
+    rng = np.random.default_rng(11)
+    with binding.OrbContext(0) as ctx:
+        for n in list(range(0, 40)) + [63, 64, 65, 100, 257, 433, 1000, 2048]:
+            for rep in range(4):
+                size = rng.integers(2, 2 + (3, 12, 200, 5)[rep], size=n)
+                ulx = 35 * rng.integers(0, (4, 40, 7, 1)[rep], size=n)
+                got = ctx.debug_sort(size, ulx)
+                want = oracle.std_sort(size, ulx)
+                assert np.array_equal(got, want), (n, rep)
+        # McIlroy's killer adversary (tests/pyref.py) drives the algorithm to its depth limit, so
+        # the heapsort fallback runs on the device too; quantised copies add ties on top
+        import ctypes as C
+        import pyref
+        heap_calls = C.c_int.in_dll(oracle.lib(), "orc_std_sort_heap_calls")
+        for n in (200, 433, 1500, 2048):
+            k = np.array(pyref.quicksort_killer(n))
+            for shift in (0, 1, 2):
+                size = (k >> shift) + 2
+                ulx = (k * 7) % 5
+                before = heap_calls.value
+                want = oracle.std_sort(size, ulx)
+                if shift == 0:
+                    assert heap_calls.value > before, "killer input did not reach the heapsort fallback"
+                assert np.array_equal(ctx.debug_sort(size, ulx), want), (n, shift)

@@ -262,3 +262,19 @@ def test_extract_counts_order_and_lapping(oracle):
     # keypoints stay >= 19 px (EDGE_THRESHOLD) inside their level
     lx = kps["x"] / np.array([g.scale[o] for o in kps["octave"]], np.float32)
     assert lx.min() >= 18.99
+
+
+def test_python_introsort_port_agrees_and_killer_reaches_heapsort(oracle):
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 16, 17, 100, 433):
+        size = rng.integers(2, 6, size=n)
+        ulx = 35 * rng.integers(0, 3, size=n)
+        items = [(int(s), int(u), i) for i, (s, u) in enumerate(zip(size, ulx))]
+        got = [t[2] for t in pyref.std_sort_py(items, lambda a, b: (a[0], a[1]) < (b[0], b[1]))]
+        assert got == list(oracle.std_sort(size, ulx))
+    heap_calls = C.c_int.in_dll(oracle.lib(), "orc_std_sort_heap_calls")
+    before = heap_calls.value
+    k = np.array(pyref.quicksort_killer(500))
+    oracle.std_sort(k + 2, np.zeros(500, int))
+    assert heap_calls.value > before
