@@ -129,10 +129,18 @@ def main():
     from send_slam_amd import binding
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal hooks for a ONE-GPU box (tests / gpurun): SENDSLAM_BENCH_BACKEND=gloo moves the two
+    # timing collectives to the CPU, SENDSLAM_BENCH_ONE_DEVICE=1 puts every rank on device 0.
+    backend = os.environ.get("SENDSLAM_BENCH_BACKEND", "nccl")
+    if os.environ.get("SENDSLAM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     # A few camera batches in flight per GPU: step i runs on context i % n (own stream, own HBM
     # buffers), so the latency-bound quadtree of one batch overlaps the dense kernels of the others.
@@ -179,7 +187,7 @@ def main():
     for c in ctxs:
         c.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -262,7 +270,7 @@ def main():
         "value": round(total_frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"1xMI355X: synthetic {w}x{h} frames, ORB extract + self-match, {nf} kp/frame",
+        "config": {"workload": f"{world}xMI355X: synthetic {w}x{h} frames, ORB extract + self-match, {nf} kp/frame",
                    "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},

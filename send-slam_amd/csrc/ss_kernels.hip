@@ -242,27 +242,25 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
      * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
      * the image are filled by BORDER_REFLECT_101 (what the blur needs; FAST never evaluates a
-     * pixel whose ring leaves the image, so it does not care). */
+     * pixel whose ring leaves the image, so it does not care).  Rows are always reflected (4
+     * ops); columns only in the tiles that touch the left / right image edge (block-uniform). */
+    const bool inner_x = x0 >= 4 && x0 + 68 <= w;
 #pragma unroll
     for (int rr = 0; rr < 3; rr++) {
         const int r = ty + 16 * rr;
         if (r < FT_ROWS) {
-            const int gy = y0 - 3 + r;
-#pragma unroll
-            for (int cc = 0; cc < 2; cc++) {
-                if (cc == 1 && tx >= 2) break;
-                const int c = cc == 0 ? tx : 16 + tx;
-                const int gx = x0 - 4 + 4 * c;
-                uint32_t v;
-                if (gy >= 0 && gy < h && gx >= 0 && gx + 3 < w) {
-                    v = *(const uint32_t *)(img + (size_t)gy * pitch + gx);
-                } else {
-                    const uint8_t *row = img + (size_t)reflect101(gy, h) * pitch;
-                    v = 0;
+            const uint8_t *row = img + (size_t)reflect101(y0 - 3 + r, h) * pitch;
+            if (inner_x) {
+                lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
+                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
+            } else {
+                for (int c = tx; c < FT_WORDS; c += 16) {
+                    const int gx = x0 - 4 + 4 * c;
+                    uint32_t v = 0;
 #pragma unroll
                     for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+                    lds[r][c] = v;
                 }
-                lds[r][c] = v;
             }
         }
     }
@@ -274,6 +272,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
      * d < -t.  Only a few % of the pixels pass; they are queued in LDS and scored in phase 2,
      * the rest get 0 without the 100-op arc search. */
     const int min_th = g->min_th;
+    uint32_t cand_bits = 0; /* bit 4*rr + i: pixel i of row 2ty+rr passed */
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
@@ -296,15 +295,16 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             const i16x2 dark = __builtin_elementwise_min(__builtin_elementwise_max(d0, d8), __builtin_elementwise_max(d4, d12));
             const i16x2 bright = __builtin_elementwise_max(__builtin_elementwise_min(d0, d8), __builtin_elementwise_min(d4, d12));
             const i16x2 c = __builtin_elementwise_max(dark, (i16x2)(0) - bright);
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                if ((int)c[hh] > min_th) {
-                    const int i = 2 * pr + hh;
-                    const int x = x0 + 4 * tx + i, y = y0 + ly;
-                    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | (4 * tx + i));
-                }
-            }
+            cand_bits |= ((int)c[0] > min_th ? 1u : 0u) << (4 * rr + 2 * pr);
+            cand_bits |= ((int)c[1] > min_th ? 1u : 0u) << (4 * rr + 2 * pr + 1);
         }
+    }
+    while (cand_bits) { /* rare: a few % of the pixels */
+        const int bit = __builtin_ctz(cand_bits);
+        cand_bits &= cand_bits - 1;
+        const int ly = 2 * ty + (bit >> 2), lx = 4 * tx + (bit & 3);
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | lx);
     }
     /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
      * window [x-3, x+4] */

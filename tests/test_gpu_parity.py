@@ -296,3 +296,52 @@ def test_device_std_sort_restatement_vs_oracle(oracle):
                 if shift == 0:
                     assert heap_calls.value > before, "killer input did not reach the heapsort fallback"
                 assert np.array_equal(ctx.debug_sort(size, ulx), want), (n, shift)
+
+
+@pytest.mark.parametrize("w,h,nf,scale,nl", [(3840, 2160, 5000, 1.2, 8), (640, 480, 800, 1.5, 5), (800, 600, 600, 2.0, 4),
+                                             (4095, 2600, 3000, 1.2, 8)])
+def test_large_images_and_other_scale_factors(oracle, w, h, nf, scale, nl):
+    """4K UHD, the widest image the packed records admit (4095 px), and pyramid scale factors
+    that take the direct (non-LDS) resize kernel."""
+    img = synth.frame(60 + nl, w, h)
+    with binding.OrbContext(0, n_features=nf, scale_factor=scale, n_levels=nl) as ctx:
+        kps, desc, counts = ctx.extract(img)
+    okps, odesc, ocounts = oracle.extract(img, oracle.default_params(n_features=nf, scale_factor=scale, n_levels=nl))
+    assert np.array_equal(counts, ocounts) and len(kps) == len(okps)
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+
+
+def test_limits_are_errors_not_truncation():
+    with binding.OrbContext(0, n_features=12000) as ctx:  # level-0 quota 2605 > 2032 sort items
+        with pytest.raises(binding.OrbError) as e:
+            ctx.extract(synth.frame(1, 640, 480))
+        assert e.value.code == binding.SS_ERR_INVALID_ARG and "quota" in str(e.value)
+    with binding.OrbContext(0) as ctx:
+        with pytest.raises(binding.OrbError) as e:
+            ctx.extract(np.zeros((100, 5000), np.uint8))
+        assert e.value.code == binding.SS_ERR_INVALID_ARG  # wider than 4095
+
+
+def test_batch_with_flat_and_textured_frames(oracle):
+    import torch
+    w, h, nf = 480, 360, 600
+    frames = np.stack([synth.frame(70, w, h), np.full((h, w), 90, np.uint8), synth.frame(71, w, h),
+                       (synth.frame(72, w, h) // 5 + 100).astype(np.uint8)])
+    d = torch.from_numpy(frames).to("cuda:0")
+    with binding.OrbContext(0, n_features=nf, max_batch=4) as ctx:
+        ctx.extract_batch_device(d.data_ptr(), 4, w, h)
+        ctx.synchronize()
+        got = [ctx.fetch_frame(b) for b in range(4)]
+        # a smaller batch on the same context afterwards must not see stale frames
+        ctx.extract_batch_device(d[2:].data_ptr(), 2, w, h)
+        ctx.synchronize()
+        again = [ctx.fetch_frame(b) for b in range(2)]
+        with pytest.raises(binding.OrbError):
+            ctx.fetch_frame(2)
+    p = oracle.default_params(n_features=nf)
+    for b in range(4):
+        okps, odesc, ocounts = oracle.extract(frames[b], p)
+        assert got[b][0].tobytes() == okps.tobytes() and np.array_equal(got[b][1], odesc) and np.array_equal(got[b][2], ocounts)
+    assert len(got[1][0]) == 0
+    for b in range(2):
+        assert again[b][0].tobytes() == got[b + 2][0].tobytes() and np.array_equal(again[b][1], got[b + 2][1])
