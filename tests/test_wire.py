@@ -225,3 +225,35 @@ def test_frontdoor_end_to_end_frames(frontdoor, oracle):
     gray = oracle.gray(np.ascontiguousarray(col), 1)
     kps, desc, _ = oracle.extract(gray, p)
     assert msgs[3]["n_keypoints"] == len(kps)
+
+
+def test_docker_cli_shim_drives_the_frontdoor_like_dockerhandler(frontdoor, tmp_path):
+    """The four docker invocations of SendSlam.DockerHandler (docker_handler.ex:117-182), answered by
+    frontdoor/run_frontdoor.sh: run -d --rm --name ... -e K=V IMAGE / inspect -f ... / logs --tail / rm -f."""
+    sh = os.path.join(ROOT, "send-slam_amd", "frontdoor", "run_frontdoor.sh")
+    env = dict(os.environ, SENDSLAM_RUN_DIR=str(tmp_path))
+    host = FakeHost()
+    try:
+        run = subprocess.run([sh, "run", "-d", "--rm", "--name", "net-orbslam", "--network=host",
+                              "-e", f"ORB_SLAM3_WS_PORT={host.port}", "-e", "ORBSLAM3_MAP_PATH=/tmp/x", "net-orbslam"],
+                             capture_output=True, text=True, env=env)
+        assert run.returncode == 0 and len(run.stdout.strip()) == 64  # an id, like `docker run -d`
+        host.accept()
+        ins = subprocess.run([sh, "inspect", "-f", "{{.State.Running}}", "net-orbslam"], capture_output=True, text=True, env=env)
+        assert ins.stdout.startswith("true")
+        dup = subprocess.run([sh, "run", "-d", "--rm", "--name", "net-orbslam", "--network=host", "net-orbslam"],
+                             capture_output=True, text=True, env=env)
+        assert dup.returncode != 0 and "already in use" in dup.stderr
+        host.send(wire.encode_payload({"type": "bogus"}))
+        import time
+        time.sleep(0.5)
+        logs = subprocess.run([sh, "logs", "--tail", "50", "net-orbslam"], capture_output=True, text=True, env=env)
+        assert "Connection established. Awaiting calibration parameters..." in logs.stdout
+        assert "unsupported type: 'bogus'" in logs.stdout
+        rm = subprocess.run([sh, "rm", "-f", "net-orbslam"], capture_output=True, text=True, env=env)
+        assert rm.returncode == 0
+        ins = subprocess.run([sh, "inspect", "-f", "{{.State.Running}}", "net-orbslam"], capture_output=True, text=True, env=env)
+        assert ins.stdout.startswith("false")
+    finally:
+        subprocess.run([sh, "rm", "-f", "net-orbslam"], capture_output=True, env=env)
+        host.close()
