@@ -886,3 +886,121 @@ void orc_match(const uint8_t *q, int nq, const uint8_t *t, int nt, int th, int r
         idx[i] = (best_j >= 0 && (th < 0 || (best <= th && best * ratio_den < second * ratio_num))) ? best_j : -1;
     }
 }
+
+/* ---- downstream of the path: pose-only optimisation (ORB-SLAM3 Optimizer::PoseOptimization,
+ * g2o EdgeSE3ProjectXYZOnlyPose) restated as damped Gauss-Newton in double precision.  Used by
+ * tests to show the north-star clause "downstream PnP pose within 1e-4 rel": fed with the HIP
+ * path's keypoints / matches it must return what it returns for the oracle's.  4 rounds x 10
+ * iterations, Huber kernel sqrt(5.991) (dropped in the last two rounds), outliers (chi2 > 5.991)
+ * re-classified after every round; pose update T <- exp([w, v]) * T. */
+static void mat3_mul(const double a[9], const double b[9], double c[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+static void se3_exp(const double d[6], double R[9], double t[3]) /* d = [omega, upsilon] */
+{
+    const double wx = d[0], wy = d[1], wz = d[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double A, B, Cc;
+    if (th < 1e-8) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; Cc = 1.0 / 6.0 - th2 / 120.0; }
+    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; Cc = (1.0 - A) / th2; }
+    const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9];
+    mat3_mul(W, W, W2);
+    double V[9];
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + A * W[i] + B * W2[i];
+        V[i] = I + B * W[i] + Cc * W2[i];
+    }
+    for (int i = 0; i < 3; i++) t[i] = V[3 * i] * d[3] + V[3 * i + 1] * d[4] + V[3 * i + 2] * d[5];
+}
+static int chol6_solve(double H[36], double b[6]) /* H x = b, H SPD; x returned in b */
+{
+    for (int j = 0; j < 6; j++) {
+        double s = H[7 * j];
+        for (int k = 0; k < j; k++) s -= H[6 * j + k] * H[6 * j + k];
+        if (s <= 0) return -1;
+        H[7 * j] = sqrt(s);
+        for (int i = j + 1; i < 6; i++) {
+            double v = H[6 * i + j];
+            for (int k = 0; k < j; k++) v -= H[6 * i + k] * H[6 * j + k];
+            H[6 * i + j] = v / H[7 * j];
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+        for (int k = 0; k < i; k++) v -= H[6 * i + k] * b[k];
+        b[i] = v / H[7 * i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double v = b[i];
+        for (int k = i + 1; k < 6; k++) v -= H[6 * k + i] * b[k];
+        b[i] = v / H[7 * i];
+    }
+    return 0;
+}
+
+/* R (row-major 3x3), t: in = initial Tcw, out = optimised.  obs in pixels, inv_sigma2 per
+ * observation.  inlier[i] receives 1/0.  Returns the number of inliers, or < 0. */
+int orc_pnp_pose_only(int n, const double *pts3d, const double *obs, const double *inv_sigma2, double fx, double fy,
+                      double cx, double cy, double R[9], double t[3], uint8_t *inlier)
+{
+    const double chi2_th = 5.991, delta = sqrt(5.991);
+    if (n < 3) return -1;
+    for (int i = 0; i < n; i++) inlier[i] = 1;
+    int n_in = n;
+    for (int round = 0; round < 4; round++) {
+        const int robust = round < 2;
+        double lambda = 1e-6;
+        for (int it = 0; it < 10; it++) {
+            double H[36] = {0}, b[6] = {0};
+            for (int i = 0; i < n; i++) {
+                if (!inlier[i]) continue;
+                const double *P = pts3d + 3 * i;
+                const double x = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
+                const double y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
+                const double z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
+                if (z <= 0) continue;
+                const double iz = 1.0 / z, iz2 = iz * iz;
+                const double ex = obs[2 * i] - (fx * x * iz + cx), ey = obs[2 * i + 1] - (fy * y * iz + cy);
+                const double w0 = inv_sigma2[i];
+                const double e2 = w0 * (ex * ex + ey * ey);
+                const double w = (robust && e2 > delta * delta) ? w0 * delta / sqrt(e2) : w0;
+                const double J0[6] = {x * y * iz2 * fx, -(1 + x * x * iz2) * fx, y * iz * fx, -iz * fx, 0, x * iz2 * fx};
+                const double J1[6] = {(1 + y * y * iz2) * fy, -x * y * iz2 * fy, -x * iz * fy, 0, -iz * fy, y * iz2 * fy};
+                for (int a = 0; a < 6; a++) {
+                    b[a] -= w * (J0[a] * ex + J1[a] * ey);
+                    for (int c = 0; c < 6; c++) H[6 * a + c] += w * (J0[a] * J0[c] + J1[a] * J1[c]);
+                }
+            }
+            for (int a = 0; a < 6; a++) H[7 * a] += lambda * (1.0 + H[7 * a]);
+            if (chol6_solve(H, b) != 0) return -2;
+            double dR[9], dt[3], Rn[9];
+            se3_exp(b, dR, dt);
+            mat3_mul(dR, R, Rn);
+            const double tn[3] = {dR[0] * t[0] + dR[1] * t[1] + dR[2] * t[2] + dt[0],
+                                  dR[3] * t[0] + dR[4] * t[1] + dR[5] * t[2] + dt[1],
+                                  dR[6] * t[0] + dR[7] * t[1] + dR[8] * t[2] + dt[2]};
+            memcpy(R, Rn, sizeof(Rn));
+            memcpy(t, tn, sizeof(tn));
+        }
+        n_in = 0;
+        for (int i = 0; i < n; i++) {
+            const double *P = pts3d + 3 * i;
+            const double x = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
+            const double y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
+            const double z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
+            double chi2 = 1e30;
+            if (z > 0) {
+                const double ex = obs[2 * i] - (fx * x / z + cx), ey = obs[2 * i + 1] - (fy * y / z + cy);
+                chi2 = inv_sigma2[i] * (ex * ex + ey * ey);
+            }
+            inlier[i] = chi2 <= chi2_th;
+            n_in += inlier[i];
+        }
+        if (n_in < 3) return -3;
+    }
+    return n_in;
+}

@@ -202,3 +202,22 @@ def std_sort(size: np.ndarray, ulx: np.ndarray) -> np.ndarray:
         items[i].size, items[i].ulx, items[i].id = int(size[i]), int(ulx[i]), i
     lib().orc_std_sort(items, n)
     return np.array([items[i].id for i in range(n)], np.int32)
+
+
+def pnp_pose_only(pts3d, obs, inv_sigma2, fx, fy, cx, cy, R0=None, t0=None):
+    """Pose-only optimisation (downstream of the path; test infrastructure).  -> (R 3x3, t 3, inlier mask)"""
+    pts3d = np.ascontiguousarray(pts3d, np.float64)
+    obs = np.ascontiguousarray(obs, np.float64)
+    inv_sigma2 = np.ascontiguousarray(inv_sigma2, np.float64)
+    n = len(pts3d)
+    R = np.ascontiguousarray(np.eye(3) if R0 is None else R0, np.float64).copy()
+    t = np.ascontiguousarray(np.zeros(3) if t0 is None else t0, np.float64).copy()
+    inl = np.zeros(n, np.uint8)
+    f = lib().orc_pnp_pose_only
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                  C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = f(n, pts3d.ctypes.data, obs.ctypes.data, inv_sigma2.ctypes.data, fx, fy, cx, cy, R.ctypes.data, t.ctypes.data,
+           inl.ctypes.data)
+    if rc < 0:
+        raise RuntimeError(f"orc_pnp_pose_only failed: {rc}")
+    return R, t, inl.astype(bool)
