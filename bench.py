@@ -230,6 +230,16 @@ def main():
         if not parity:
             sys.exit("bench.py: GPU results differ from the oracle on the benchmark frames")
 
+    # Latency path of the drop-in boundary (what the NIF / front door call per camera frame):
+    # host pixels in, host keypoints + descriptors out, PCIe copies included.  Never `value`.
+    lat = []
+    for i in range(12):
+        t1 = time.perf_counter()
+        ctx.extract(frames[i % B])
+        lat.append(time.perf_counter() - t1)
+    lat = sorted(lat[2:])
+    single_frame_ms = lat[len(lat) // 2] * 1e3
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -275,6 +285,7 @@ def main():
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+        "single_frame_host_to_host_ms": round(single_frame_ms, 3),
     }
     print(json.dumps(out))
     if world > 1:
