@@ -274,6 +274,19 @@ def main():
                             "contract asks for it, not because HBM limits it; 'achieved' is live with several batches "
                             "in flight, 'achieved_isolated' is the same kernel alone on the chip"}
 
+    # the Hamming-match kernel against the resource that actually bounds it: integer VALU issue.
+    # Peak = register-resident XOR + popcount loop measured on this chip (profiles/r01_peaks.json,
+    # profiles/tools/peaks_probe.hip); work = 22 VALU lane-ops per (query, train) pair.
+    int_roofline = None
+    mk = next((k for k in kernels if k["name"] == "match"), None)
+    ppath = os.path.join(ROOT, "profiles", "r01_peaks.json")
+    if mk and mk.get("isolated_mean_ms") and os.path.exists(ppath):
+        peak = json.load(open(ppath))["xor_popc_lane_ops_per_s"]
+        pairs = B * float(nf) ** 2  # the quotas are saturated on these frames (2000 <= n <= 2024)
+        ach = pairs * 22 / (mk["isolated_mean_ms"] * 1e-3)
+        int_roofline = {"kernel": "match", "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
+                        "unit": "lane-ops/s", "frac": round(ach / peak, 4), "ops_per_pair": 22}
+
     total_frames = B * a.steps * world
     out = {
         "metric": "frames/sec ORB extract+match @1280x720, 2000 kp/frame",
@@ -284,7 +297,7 @@ def main():
                    "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
-        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+        "roofline": roofline, "int_valu_roofline": int_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
         "single_frame_host_to_host_ms": round(single_frame_ms, 3),
     }
     print(json.dumps(out))
