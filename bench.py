@@ -96,6 +96,61 @@ def cpu_baseline(frames, nf, budget_s=12.0):
     return obj, outs
 
 
+def bench_loop_closure(a):
+    """Config 5 of BASELINE.json: query-vs-all Hamming match against a keyframe database partitioned
+    in contiguous slabs over the ranks; one broadcast + one all_gather per query (multi.py)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from send_slam_amd import binding, multi
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("SENDSLAM_BENCH_BACKEND", "nccl")
+    if os.environ.get("SENDSLAM_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    n_db, nq = 10000 * 2000, a.features
+    b, e = multi.slab(n_db, world, rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    db = torch.randint(0, 256, (e - b, 32), dtype=torch.uint8, device=dev, generator=gen)
+    query = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gen)
+    ctx = binding.OrbContext(local_rank)
+    local = multi.hip_local_match(ctx)
+    for _ in range(a.warmup):
+        multi.loop_closure_query(query, db, b, local)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        idx, d1, d2 = multi.loop_closure_query(query, db, b, local)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "loop-closure queries/sec (2000 descriptors vs 10k-keyframe database)", "value": round(a.steps / elapsed, 3),
+            "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
+                                   "raw local match + all_gather of (d1, j1, d2) + fold", "parallelism": f"db slabs x {world}"},
+            "pairs_per_s": float(f"{nq * n_db * a.steps / elapsed:.4g}")}))
+    ctx.close()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,7 +162,12 @@ def main():
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--contexts", type=int, default=3, help="camera batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="extract_match", choices=["extract_match", "loop_closure"],
+                    help="extract_match = the BASELINE.json metric (default); loop_closure = config 5: one 2000-descriptor "
+                         "query against a 10 000-keyframe descriptor database sharded over the ranks (strong scaling)")
     a = ap.parse_args()
+    if a.workload == "loop_closure":
+        return bench_loop_closure(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -380,3 +380,19 @@ def test_downstream_pnp_pose_from_hip_outputs(oracle):
     # the pair is the same scene shifted by (+3, -2) px: t = (3 Z / fx, -2 Z / fy, 0), R = I
     assert np.abs(t_h - np.array([3 * Z / fx, -2 * Z / fy, 0.0])).max() < 5e-3  # keypoints are integer pixels x scale
     assert np.abs(R_h - np.eye(3)).max() < 2e-3
+
+
+def test_contexts_do_not_leak_device_memory():
+    import torch
+    img = synth.frame(5, 640, 480)
+    torch.cuda.synchronize()
+    with binding.OrbContext(0) as ctx:  # warm the runtime's own pools
+        ctx.extract(img)
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(25):
+        with binding.OrbContext(0, max_batch=4) as ctx:
+            ctx.extract(img)
+            ctx.extract(synth.frame(6, 320, 240))  # geometry rebuild on a size change
+            ctx.match(np.zeros((10, 32), np.uint8), np.zeros((300000, 32), np.uint8))
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 contexts"
