@@ -600,105 +600,20 @@ __device__ void sort_heap_range(uint64_t *first, int n)
         sort_adjust_heap(first, 0, last, v);
     }
 }
-__device__ __forceinline__ void sort_unguarded_linear_insert(uint64_t *a, int last)
-{
-    const uint64_t val = a[last];
-    int next = last - 1;
-    while (item_less(val, a[next])) {
-        a[last] = a[next];
-        last = next;
-        --next;
-    }
-    a[last] = val;
-}
-__device__ void sort_insertion(uint64_t *a, int first, int last)
-{
-    if (first == last) return;
-    for (int i = first + 1; i != last; ++i) {
-        if (item_less(a[i], a[first])) {
-            const uint64_t val = a[i];
-            for (int k = i; k > first; --k) a[k] = a[k - 1];
-            a[first] = val;
-        } else
-            sort_unguarded_linear_insert(a, i);
-    }
-}
-/* std::sort(a, a + n, compareNodes), single lane */
-__device__ void std_sort_items(uint64_t *a, int n)
-{
-    if (n <= 0) return;
-    int lg = 0;
-    for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
-    /* __introsort_loop with an explicit stack for the recursive (right) halves */
-    int stack_first[64], stack_last[64], stack_depth[64];
-    int sp = 0;
-    stack_first[0] = 0;
-    stack_last[0] = n;
-    stack_depth[0] = lg * 2;
-    sp = 1;
-    while (sp > 0) {
-        --sp;
-        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
-        while (last - first > 16) {
-            if (depth == 0) {
-                sort_heap_range(a + first, last - first);
-                break;
-            }
-            --depth;
-            const int mid = first + (last - first) / 2;
-            const int ia = first + 1, ib = mid, ic = last - 1;
-            int pick; /* __move_median_to_first */
-            if (item_less(a[ia], a[ib])) {
-                if (item_less(a[ib], a[ic])) pick = ib;
-                else if (item_less(a[ia], a[ic])) pick = ic;
-                else pick = ia;
-            } else if (item_less(a[ia], a[ic])) pick = ia;
-            else if (item_less(a[ib], a[ic])) pick = ic;
-            else pick = ib;
-            {
-                const uint64_t tmp = a[first];
-                a[first] = a[pick];
-                a[pick] = tmp;
-            }
-            int lo = first + 1, hi = last; /* __unguarded_partition */
-            for (;;) {
-                while (item_less(a[lo], a[first])) ++lo;
-                --hi;
-                while (item_less(a[first], a[hi])) --hi;
-                if (!(lo < hi)) break;
-                const uint64_t tmp = a[lo];
-                a[lo] = a[hi];
-                a[hi] = tmp;
-                ++lo;
-            }
-            if (sp < 64) {
-                stack_first[sp] = lo;
-                stack_last[sp] = last;
-                stack_depth[sp] = depth;
-                ++sp;
-            }
-            last = lo;
-        }
-    }
-    if (n > 16) {
-        sort_insertion(a, 0, 16);
-        for (int i = 16; i != n; ++i) sort_unguarded_linear_insert(a, i);
-    } else
-        sort_insertion(a, 0, n);
-}
-
-/* One wave per tree: lanes hand data to each other through memory, but a wave's memory
- * instructions are issued and serviced in program order (LLVM AMDGPU memory model: wavefront
- * scope needs no cache action or wait), so only the COMPILER must be kept from moving accesses.
- * No s_waitcnt vmcnt(0), no s_barrier: a dependent load simply waits for its own data. */
+/* Lanes of ONE wave hand data to each other through memory: a wave's memory instructions are
+ * issued and serviced in program order (LLVM AMDGPU memory model: wavefront scope needs no cache
+ * action or wait), so only the COMPILER must be kept from moving accesses.  No s_waitcnt vmcnt(0),
+ * no s_barrier: a dependent load simply waits for its own data. */
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-/* The same std::sort, executed by ONE WAVE instead of one lane: identical sequence of element
- * moves (so identical placement of equal keys), but the two inner scans of the partition and the
+/* libstdc++ std::sort(first, last, compareNodes) -- introsort: median-of-3 partitions down to 16
+ * elements with a 2*lg(n) depth limit (heapsort beyond it), then one insertion pass -- executed by
+ * ONE WAVE: the sequence of element moves is the sequential algorithm's (so equal keys land exactly
+ * where libstdc++ leaves them), but the two inner scans of the partition and the
  * shift of the insertion step look at up to 64 elements per LDS round trip (ballot + count
  * trailing zeros) instead of one.  Control flow is wave-uniform. */
 __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src_lane)
