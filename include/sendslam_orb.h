@@ -19,6 +19,8 @@
  *                              which handles one camera on one thread :594)
  *   ss_match*                  ORBmatcher::DescriptorDistance + best/second-best search inside
  *                              TrackMonocular :594 (all-pairs rule: SURVEY.md Appendix A.6)
+ *   ss_track                   TrackMonocular :594 -> Twc, tracking state :596 (bounded monocular
+ *                              front-end; the pose SendPosePacket :225-282 ships)
  *   ss_stats                   vTimesTrack median/mean summary :615-616, :656-664
  *   ss_last_error              the cerr diagnostics of the shim (:457-469, :523-551)
  *
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2
 #define SS_MAX_LEVELS 16
 #define SS_DESC_BYTES 32
 
@@ -166,6 +168,31 @@ int ss_match_device(ss_ctx *ctx, const void *d_query, int n_query, const void *d
  * device arrays [n_frames][kp_capacity]; rows >= n_keypoints[b] are idx -1. */
 int ss_match_batch_device(ss_ctx *ctx, int mode, int th, int ratio_num, int ratio_den,
                           void *d_idx, void *d_d1, void *d_d2);
+
+/* Pose of one frame (shim :225-282 SendPosePacket: position + quaternion x y z w of Twc, shipped
+ * only in tracking state OK :596).  tracking_state uses ORB_SLAM3::Tracking::eTrackingState values:
+ * 0 NO_IMAGES_YET, 1 NOT_INITIALIZED, 2 OK, 4 LOST. */
+typedef struct {
+    int32_t tracking_state;
+    int32_t camera_id;
+    double timestamp;
+    double position[3];
+    double quaternion[4]; /* x y z w */
+    int32_t n_keypoints;
+    int32_t n_matches;    /* one-to-one matches to the reference / previous frame */
+    int32_t n_inliers;    /* triangulated (initialisation) or pose-optimisation inliers */
+    int32_t n_map_points; /* keypoints of this frame that carry a 3-D point */
+} ss_pose;
+
+/* The whole "frame" branch :521-627 = TrackMonocular :594 for a bounded monocular front-end:
+ * ss_extract, device match against the initial / previous frame's descriptors (th 50, ratio
+ * 0.9), then host double-precision geometry (csrc/ss_track.h: two-view initialisation, pose-only
+ * optimisation, triangulation).  Requires ss_set_calibration (fx fy cx cy k1 k2 p1 p2 are used).
+ * No keyframes, local mapping, loop closing or relocalisation. */
+int ss_track(ss_ctx *ctx, int camera_id, const uint8_t *pix, int width, int height, int channels,
+             int row_stride, double timestamp, ss_pose *out);
+/* back to NO_IMAGES_YET (System::Reset / the "terminate" message :462-469) */
+int ss_track_reset(ss_ctx *ctx);
 
 int ss_synchronize(ss_ctx *ctx);
 /* the hipStream_t every kernel of this context is launched on */

@@ -20,6 +20,7 @@
 #include "ss_geometry.h"
 #include "ss_kernels.h"
 #include "ss_layout.h"
+#include "ss_track.h"
 
 namespace {
 
@@ -83,6 +84,14 @@ struct ss_ctx {
     std::vector<int32_t> h_err;
 
     int last_n_frames = 0;
+
+    /* ss_track: descriptors of the initialisation reference / the previous frame, host geometry */
+    uint8_t *d_ref_desc = nullptr, *d_prev_desc = nullptr;
+    size_t d_ref_desc_bytes = 0, d_prev_desc_bytes = 0;
+    sst_tracker tracker;
+    std::vector<float> h_xy;
+    std::vector<int32_t> h_oct, h_midx;
+    std::vector<uint16_t> h_md1;
 
     bool profile = false;
     std::vector<stage_rec> stages;
@@ -398,6 +407,8 @@ int ss_destroy(ss_ctx *c)
     dev_free(c->d_mq);
     dev_free(c->d_mt);
     dev_free(c->d_mout);
+    dev_free(c->d_ref_desc);
+    dev_free(c->d_prev_desc);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SS_OK;
@@ -593,6 +604,70 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
                   c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
     }
     HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height, int channels, int row_stride,
+             double timestamp, ss_pose *out)
+{
+    if (!c || !out) return SS_ERR_INVALID_ARG;
+    if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    ss_frame_result res;
+    int rc = ss_extract(c, camera_id, pix, width, height, channels, row_stride, timestamp, &res);
+    if (rc != SS_OK) return rc;
+    const int n = res.n_keypoints;
+    sst_tracker &tr = c->tracker;
+    tr.cam = sst_camera{c->cam.fx, c->cam.fy, c->cam.cx, c->cam.cy, c->cam.k1, c->cam.k2, c->cam.p1, c->cam.p2};
+    tr.scale_factor = c->params.scale_factor;
+    c->h_xy.resize((size_t)2 * std::max(n, 1));
+    c->h_oct.resize((size_t)std::max(n, 1));
+    c->h_midx.assign((size_t)std::max(n, 1), -1);
+    c->h_md1.assign((size_t)std::max(n, 1), 0xFFFF);
+    for (int i = 0; i < n; i++) {
+        c->h_xy[2 * i] = res.keypoints[i].x;
+        c->h_xy[2 * i + 1] = res.keypoints[i].y;
+        c->h_oct[i] = res.keypoints[i].octave;
+    }
+    const int want = tr.want_match();
+    if (want != SST_MATCH_NONE && n > 0) {
+        /* this frame's descriptors are still in HBM (frame 0 of the batch arrays) */
+        const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : c->d_prev_desc;
+        rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n * 8);
+        if (rc != SS_OK) return rc;
+        int32_t *di = (int32_t *)c->d_mout;
+        uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
+        rc = ss_match_device(c, c->desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+        if (rc != SS_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->h_midx.data(), di, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_md1.data(), dd1, (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    sst_pose_out po;
+    const int keep = tr.step(n, c->h_xy.data(), c->h_oct.data(), c->h_midx.data(), c->h_md1.data(), po);
+    if (keep != SST_KEEP_NONE && n > 0) {
+        uint8_t *&dst = keep == SST_KEEP_AS_REF ? c->d_ref_desc : c->d_prev_desc;
+        size_t &dst_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_bytes : c->d_prev_desc_bytes;
+        rc = grow(c, dst, dst_bytes, (size_t)n * SS_DESC_BYTES);
+        if (rc != SS_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(dst, c->desc, (size_t)n * SS_DESC_BYTES, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    out->tracking_state = po.state;
+    out->camera_id = camera_id;
+    out->timestamp = timestamp;
+    for (int k = 0; k < 3; k++) out->position[k] = po.pos[k];
+    for (int k = 0; k < 4; k++) out->quaternion[k] = po.quat[k];
+    out->n_keypoints = n;
+    out->n_matches = po.n_matches;
+    out->n_inliers = po.n_inliers;
+    out->n_map_points = po.n_map_points;
+    return SS_OK;
+}
+
+int ss_track_reset(ss_ctx *c)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    c->tracker.reset();
     return SS_OK;
 }
 

@@ -1,0 +1,919 @@
+/*
+ * ss_track.cpp -- pose from matches: undistortion, two-view reconstruction, pose-only
+ * optimisation, triangulation.  See ss_track.h for what each routine restates and why this is
+ * host code (small dense double-precision math on <= 2000 points per frame).
+ * Linear algebra is a cyclic Jacobi eigen-solver on small symmetric matrices (n <= 9): it yields
+ * the null vectors of the DLT systems and the 3x3 SVDs, with no external library.
+ */
+#include "ss_track.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+/* eigen-decomposition of a symmetric n x n matrix (row-major), ascending eigenvalues; V columns */
+void jacobi_eig(int n, const double *A_in, double *eval, double *V)
+{
+    double A[81];
+    memcpy(A, A_in, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) (i == j ? diag : off) += A[i * n + j] * A[i * n + j];
+        if (off <= 1e-30 * (diag > 0 ? diag : 1.0)) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int order[9];
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::sort(order, order + n, [&](int a, int b) { return A[a * n + a] < A[b * n + b]; });
+    double Vs[81];
+    for (int k = 0; k < n; k++) {
+        eval[k] = A[order[k] * n + order[k]];
+        for (int i = 0; i < n; i++) Vs[i * n + k] = V[i * n + order[k]];
+    }
+    memcpy(V, Vs, sizeof(double) * (size_t)n * n);
+}
+
+/* unit null vector (smallest singular vector) of an m x n system, n <= 9 */
+void null_vector(int m, int n, const double *A, double *x)
+{
+    double AtA[81] = {0}, ev[9], V[81];
+    for (int r = 0; r < m; r++)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) AtA[i * n + j] += A[r * n + i] * A[r * n + j];
+    jacobi_eig(n, AtA, ev, V);
+    for (int i = 0; i < n; i++) x[i] = V[i * n + 0];
+}
+
+void mat3_mul(const double *a, const double *b, double *c)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+void mat3_t(const double *a, double *c)
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c[3 * i + j] = a[3 * j + i];
+}
+double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+/* M = U diag(s) V^T, s descending; third left vector completed by a cross product when s3 ~ 0 */
+void svd3(const double *M, double *U, double *s, double *V)
+{
+    double MtM[9], Mt[9], ev[3], Ve[9];
+    mat3_t(M, Mt);
+    mat3_mul(Mt, M, MtM);
+    jacobi_eig(3, MtM, ev, Ve);
+    for (int k = 0; k < 3; k++) { /* descending */
+        const int src = 2 - k;
+        s[k] = std::sqrt(ev[src] > 0 ? ev[src] : 0.0);
+        for (int i = 0; i < 3; i++) V[3 * i + k] = Ve[3 * i + src];
+    }
+    for (int k = 0; k < 2; k++) {
+        double u[3];
+        for (int i = 0; i < 3; i++) u[i] = M[3 * i] * V[k] + M[3 * i + 1] * V[3 + k] + M[3 * i + 2] * V[6 + k];
+        const double nrm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        for (int i = 0; i < 3; i++) U[3 * i + k] = nrm > 0 ? u[i] / nrm : (i == k ? 1.0 : 0.0);
+    }
+    U[2] = U[3 * 1 + 0] * U[3 * 2 + 1] - U[3 * 2 + 0] * U[3 * 1 + 1];
+    U[5] = U[3 * 2 + 0] * U[3 * 0 + 1] - U[3 * 0 + 0] * U[3 * 2 + 1];
+    U[8] = U[3 * 0 + 0] * U[3 * 1 + 1] - U[3 * 1 + 0] * U[3 * 0 + 1];
+}
+
+struct lcg { /* deterministic sampler (the reference seeds rand() with 0; any fixed generator serves) */
+    uint64_t x;
+    uint32_t next(uint32_t mod)
+    {
+        x = x * 6364136223846793005ull + 1442695040888963407ull;
+        return (uint32_t)((x >> 33) % mod);
+    }
+};
+
+void normalize_pts(int n, const double *p, std::vector<double> &out, double T[9])
+{
+    double mx = 0, my = 0;
+    for (int i = 0; i < n; i++) { mx += p[2 * i]; my += p[2 * i + 1]; }
+    mx /= n; my /= n;
+    double dx = 0, dy = 0;
+    out.resize((size_t)2 * n);
+    for (int i = 0; i < n; i++) {
+        out[2 * i] = p[2 * i] - mx;
+        out[2 * i + 1] = p[2 * i + 1] - my;
+        dx += std::fabs(out[2 * i]);
+        dy += std::fabs(out[2 * i + 1]);
+    }
+    dx /= n; dy /= n;
+    const double sx = 1.0 / dx, sy = 1.0 / dy;
+    for (int i = 0; i < n; i++) { out[2 * i] *= sx; out[2 * i + 1] *= sy; }
+    const double Tm[9] = {sx, 0, -mx * sx, 0, sy, -my * sy, 0, 0, 1};
+    memcpy(T, Tm, sizeof(Tm));
+}
+
+void compute_f21(const double *p1, const double *p2, const int idx[8], double F[9])
+{
+    double A[8 * 9];
+    for (int k = 0; k < 8; k++) {
+        const double u1 = p1[2 * idx[k]], v1 = p1[2 * idx[k] + 1], u2 = p2[2 * idx[k]], v2 = p2[2 * idx[k] + 1];
+        double *r = A + 9 * k;
+        r[0] = u2 * u1; r[1] = u2 * v1; r[2] = u2; r[3] = v2 * u1; r[4] = v2 * v1; r[5] = v2; r[6] = u1; r[7] = v1; r[8] = 1;
+    }
+    double f[9];
+    null_vector(8, 9, A, f);
+    double U[9], s[3], V[9];
+    svd3(f, U, s, V);
+    s[2] = 0; /* rank 2 */
+    double US[9], Vt[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) US[3 * i + j] = U[3 * i + j] * s[j];
+    mat3_t(V, Vt);
+    mat3_mul(US, Vt, F);
+}
+
+double check_fundamental(const double *F, int n, const double *x1, const double *x2, std::vector<uint8_t> &inl)
+{
+    const double th = 3.841, th_score = 5.991, inv_sigma2 = 1.0;
+    double score = 0;
+    inl.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        bool in = true;
+        const double a2 = F[0] * u1 + F[1] * v1 + F[2], b2 = F[3] * u1 + F[4] * v1 + F[5], c2 = F[6] * u1 + F[7] * v1 + F[8];
+        const double num2 = a2 * u2 + b2 * v2 + c2;
+        const double chi1 = num2 * num2 / (a2 * a2 + b2 * b2) * inv_sigma2;
+        if (chi1 > th) in = false; else score += th_score - chi1;
+        const double a1 = F[0] * u2 + F[3] * v2 + F[6], b1 = F[1] * u2 + F[4] * v2 + F[7], c1 = F[2] * u2 + F[5] * v2 + F[8];
+        const double num1 = a1 * u1 + b1 * v1 + c1;
+        const double chi2 = num1 * num1 / (a1 * a1 + b1 * b1) * inv_sigma2;
+        if (chi2 > th) in = false; else score += th_score - chi2;
+        inl[i] = in;
+    }
+    return score;
+}
+
+/* linear triangulation with P = K [R | t]; returns false if the homogeneous weight vanishes */
+bool triangulate_dlt(const sst_camera &c, const double x1[2], const double x2[2], const double R1[9], const double t1[3],
+                     const double R2[9], const double t2[3], double X[3])
+{
+    double P1[12], P2[12];
+    const double K[9] = {c.fx, 0, c.cx, 0, c.fy, c.cy, 0, 0, 1};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++) {
+            double a = 0, b = 0;
+            for (int k = 0; k < 3; k++) {
+                a += K[3 * i + k] * (j < 3 ? R1[3 * k + j] : t1[k]);
+                b += K[3 * i + k] * (j < 3 ? R2[3 * k + j] : t2[k]);
+            }
+            P1[4 * i + j] = a;
+            P2[4 * i + j] = b;
+        }
+    double A[16];
+    for (int j = 0; j < 4; j++) {
+        A[j] = x1[0] * P1[8 + j] - P1[j];
+        A[4 + j] = x1[1] * P1[8 + j] - P1[4 + j];
+        A[8 + j] = x2[0] * P2[8 + j] - P2[j];
+        A[12 + j] = x2[1] * P2[8 + j] - P2[4 + j];
+    }
+    double h[4];
+    null_vector(4, 4, A, h);
+    if (h[3] == 0 || !std::isfinite(h[3])) return false;
+    X[0] = h[0] / h[3]; X[1] = h[1] / h[3]; X[2] = h[2] / h[3];
+    return std::isfinite(X[0]) && std::isfinite(X[1]) && std::isfinite(X[2]);
+}
+
+int check_rt(const sst_camera &c, const double R[9], const double t[3], int n, const double *x1, const double *x2,
+             const std::vector<uint8_t> &inl, double th2, std::vector<double> &p3d, std::vector<uint8_t> &good, double &parallax)
+{
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+    const double O2[3] = {-(R[0] * t[0] + R[3] * t[1] + R[6] * t[2]), -(R[1] * t[0] + R[4] * t[1] + R[7] * t[2]),
+                          -(R[2] * t[0] + R[5] * t[1] + R[8] * t[2])};
+    p3d.assign((size_t)3 * n, 0.0);
+    good.assign((size_t)n, 0);
+    std::vector<double> cosp;
+    int n_good = 0;
+    for (int i = 0; i < n; i++) {
+        if (!inl[i]) continue;
+        double X[3];
+        if (!triangulate_dlt(c, x1 + 2 * i, x2 + 2 * i, I, z3, R, t, X)) continue;
+        const double n2[3] = {X[0] - O2[0], X[1] - O2[1], X[2] - O2[2]};
+        const double d1 = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
+        const double d2 = std::sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+        const double cp = (X[0] * n2[0] + X[1] * n2[1] + X[2] * n2[2]) / (d1 * d2);
+        if (X[2] <= 0 && cp < 0.99998) continue;
+        const double Y[3] = {R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1],
+                             R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2]};
+        if (Y[2] <= 0 && cp < 0.99998) continue;
+        const double e1x = c.fx * X[0] / X[2] + c.cx - x1[2 * i], e1y = c.fy * X[1] / X[2] + c.cy - x1[2 * i + 1];
+        if (e1x * e1x + e1y * e1y > th2) continue;
+        const double e2x = c.fx * Y[0] / Y[2] + c.cx - x2[2 * i], e2y = c.fy * Y[1] / Y[2] + c.cy - x2[2 * i + 1];
+        if (e2x * e2x + e2y * e2y > th2) continue;
+        cosp.push_back(cp);
+        p3d[3 * i] = X[0]; p3d[3 * i + 1] = X[1]; p3d[3 * i + 2] = X[2];
+        n_good++;
+        if (cp < 0.99998) good[i] = 1;
+    }
+    parallax = 0;
+    if (n_good > 0) {
+        std::sort(cosp.begin(), cosp.end());
+        const size_t k = std::min<size_t>(50, cosp.size() - 1);
+        parallax = std::acos(cosp[k]) * 180.0 / 3.14159265358979323846;
+    }
+    return n_good;
+}
+
+void se3_exp(const double d[6], double R[9], double t[3])
+{
+    const double wx = d[0], wy = d[1], wz = d[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+    double A, B, Cc;
+    if (th < 1e-8) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; Cc = 1.0 / 6.0 - th2 / 120.0; }
+    else { A = std::sin(th) / th; B = (1.0 - std::cos(th)) / th2; Cc = (1.0 - A) / th2; }
+    const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9], V[9];
+    mat3_mul(W, W, W2);
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + A * W[i] + B * W2[i];
+        V[i] = I + B * W[i] + Cc * W2[i];
+    }
+    for (int i = 0; i < 3; i++) t[i] = V[3 * i] * d[3] + V[3 * i + 1] * d[4] + V[3 * i + 2] * d[5];
+}
+
+bool chol6_solve(double H[36], double b[6])
+{
+    for (int j = 0; j < 6; j++) {
+        double s = H[7 * j];
+        for (int k = 0; k < j; k++) s -= H[6 * j + k] * H[6 * j + k];
+        if (s <= 0) return false;
+        H[7 * j] = std::sqrt(s);
+        for (int i = j + 1; i < 6; i++) {
+            double v = H[6 * i + j];
+            for (int k = 0; k < j; k++) v -= H[6 * i + k] * H[6 * j + k];
+            H[6 * i + j] = v / H[7 * j];
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+        for (int k = 0; k < i; k++) v -= H[6 * i + k] * b[k];
+        b[i] = v / H[7 * i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double v = b[i];
+        for (int k = i + 1; k < 6; k++) v -= H[6 * k + i] * b[k];
+        b[i] = v / H[7 * i];
+    }
+    return true;
+}
+
+} // namespace
+
+void sst_undistort(const sst_camera &c, int n, const float *xy_in, double *xy_out)
+{
+    const bool none = c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0;
+    for (int i = 0; i < n; i++) {
+        if (none) {
+            xy_out[2 * i] = xy_in[2 * i];
+            xy_out[2 * i + 1] = xy_in[2 * i + 1];
+            continue;
+        }
+        const double x0 = (xy_in[2 * i] - c.cx) / c.fx, y0 = (xy_in[2 * i + 1] - c.cy) / c.fy;
+        double x = x0, y = y0;
+        for (int it = 0; it < 5; it++) { /* cv::undistortPoints fixed-point iteration */
+            const double r2 = x * x + y * y;
+            const double icdist = 1.0 / (1.0 + (c.k2 * r2 + c.k1) * r2);
+            const double dx = 2 * c.p1 * x * y + c.p2 * (r2 + 2 * x * x);
+            const double dy = c.p1 * (r2 + 2 * y * y) + 2 * c.p2 * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        xy_out[2 * i] = x * c.fx + c.cx;
+        xy_out[2 * i + 1] = y * c.fy + c.cy;
+    }
+}
+
+int sst_two_view(const sst_camera &c, int n, const double *x1, const double *x2, double R[9], double t[3],
+                 std::vector<uint8_t> &triangulated, std::vector<double> &pts3d)
+{
+    triangulated.assign((size_t)n, 0);
+    pts3d.assign((size_t)3 * n, 0.0);
+    if (n < 8) return 0;
+    std::vector<double> n1, n2;
+    double T1[9], T2[9], T2t[9];
+    normalize_pts(n, x1, n1, T1);
+    normalize_pts(n, x2, n2, T2);
+    mat3_t(T2, T2t);
+
+    /* FindFundamental: 200 RANSAC rounds of the normalised 8-point algorithm */
+    lcg rng{0x9E3779B97F4A7C15ull};
+    std::vector<int> avail((size_t)n);
+    std::vector<uint8_t> inl, best_inl;
+    double best_score = -1, best_F[9] = {0};
+    for (int it = 0; it < 200; it++) {
+        for (int i = 0; i < n; i++) avail[i] = i;
+        int idx[8], na = n;
+        for (int j = 0; j < 8; j++) {
+            const int r = (int)rng.next((uint32_t)na);
+            idx[j] = avail[r];
+            avail[r] = avail[na - 1];
+            na--;
+        }
+        double Fn[9], tmp[9], F[9];
+        compute_f21(n1.data(), n2.data(), idx, Fn);
+        mat3_mul(T2t, Fn, tmp);
+        mat3_mul(tmp, T1, F);
+        const double score = check_fundamental(F, n, x1, x2, inl);
+        if (score > best_score) {
+            best_score = score;
+            best_inl = inl;
+            memcpy(best_F, F, sizeof(F));
+        }
+    }
+    int N = 0;
+    for (uint8_t b : best_inl) N += b;
+    if (N < 8) return 0;
+
+    /* ReconstructF */
+    const double K[9] = {c.fx, 0, c.cx, 0, c.fy, c.cy, 0, 0, 1};
+    double Kt[9], tmp[9], E[9];
+    mat3_t(K, Kt);
+    mat3_mul(Kt, best_F, tmp);
+    mat3_mul(tmp, K, E);
+    double U[9], s[3], V[9], Vt[9];
+    svd3(E, U, s, V);
+    mat3_t(V, Vt);
+    double tt[3] = {U[2], U[5], U[8]};
+    const double tn = std::sqrt(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
+    for (double &v : tt) v /= tn;
+    const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    double R1[9], R2[9];
+    mat3_mul(U, W, tmp);
+    mat3_mul(tmp, Vt, R1);
+    mat3_mul(U, Wt, tmp);
+    mat3_mul(tmp, Vt, R2);
+    if (det3(R1) < 0) for (double &v : R1) v = -v;
+    if (det3(R2) < 0) for (double &v : R2) v = -v;
+    const double t1[3] = {tt[0], tt[1], tt[2]}, t2[3] = {-tt[0], -tt[1], -tt[2]};
+    const double *Rs[4] = {R1, R2, R1, R2};
+    const double *ts[4] = {t1, t1, t2, t2};
+    std::vector<double> p3d[4];
+    std::vector<uint8_t> good[4];
+    int n_good[4];
+    double parallax[4];
+    for (int k = 0; k < 4; k++) n_good[k] = check_rt(c, Rs[k], ts[k], n, x1, x2, best_inl, 4.0, p3d[k], good[k], parallax[k]);
+    const int max_good = std::max(std::max(n_good[0], n_good[1]), std::max(n_good[2], n_good[3]));
+    const int n_min_good = std::max((int)(0.9 * N), 50);
+    int n_similar = 0;
+    for (int k = 0; k < 4; k++) n_similar += n_good[k] > 0.7 * max_good;
+    if (max_good < n_min_good || n_similar > 1) return 0;
+    for (int k = 0; k < 4; k++) {
+        if (n_good[k] != max_good) continue;
+        if (parallax[k] <= 1.0) return 0;
+        memcpy(R, Rs[k], sizeof(double) * 9);
+        memcpy(t, ts[k], sizeof(double) * 3);
+        triangulated = good[k];
+        pts3d = p3d[k];
+        int cnt = 0;
+        for (uint8_t b : triangulated) cnt += b;
+        return cnt;
+    }
+    return 0;
+}
+
+int sst_pose_only(int n, const double *pts3d, const double *obs, const double *inv_sigma2, const sst_camera &c,
+                  double R[9], double t[3], std::vector<uint8_t> &inlier)
+{
+    const double chi2_th = 5.991, delta = std::sqrt(5.991);
+    inlier.assign((size_t)n, 1);
+    if (n < 3) return -1;
+    int n_in = n;
+    for (int round = 0; round < 4; round++) {
+        const bool robust = round < 2;
+        const double lambda = 1e-6;
+        for (int it = 0; it < 10; it++) {
+            double H[36] = {0}, b[6] = {0};
+            for (int i = 0; i < n; i++) {
+                if (!inlier[i]) continue;
+                const double *P = pts3d + 3 * i;
+                const double x = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
+                const double y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
+                const double z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
+                if (z <= 0) continue;
+                const double iz = 1.0 / z, iz2 = iz * iz;
+                const double ex = obs[2 * i] - (c.fx * x * iz + c.cx), ey = obs[2 * i + 1] - (c.fy * y * iz + c.cy);
+                const double w0 = inv_sigma2[i];
+                const double e2 = w0 * (ex * ex + ey * ey);
+                const double w = (robust && e2 > delta * delta) ? w0 * delta / std::sqrt(e2) : w0;
+                const double J0[6] = {x * y * iz2 * c.fx, -(1 + x * x * iz2) * c.fx, y * iz * c.fx, -iz * c.fx, 0, x * iz2 * c.fx};
+                const double J1[6] = {(1 + y * y * iz2) * c.fy, -x * y * iz2 * c.fy, -x * iz * c.fy, 0, -iz * c.fy, y * iz2 * c.fy};
+                for (int a = 0; a < 6; a++) {
+                    b[a] -= w * (J0[a] * ex + J1[a] * ey);
+                    for (int cc = 0; cc < 6; cc++) H[6 * a + cc] += w * (J0[a] * J0[cc] + J1[a] * J1[cc]);
+                }
+            }
+            for (int a = 0; a < 6; a++) H[7 * a] += lambda * (1.0 + H[7 * a]);
+            if (!chol6_solve(H, b)) return -2;
+            double dR[9], dt[3], Rn[9];
+            se3_exp(b, dR, dt);
+            mat3_mul(dR, R, Rn);
+            const double tn[3] = {dR[0] * t[0] + dR[1] * t[1] + dR[2] * t[2] + dt[0], dR[3] * t[0] + dR[4] * t[1] + dR[5] * t[2] + dt[1],
+                                  dR[6] * t[0] + dR[7] * t[1] + dR[8] * t[2] + dt[2]};
+            memcpy(R, Rn, sizeof(Rn));
+            memcpy(t, tn, sizeof(tn));
+        }
+        n_in = 0;
+        for (int i = 0; i < n; i++) {
+            const double *P = pts3d + 3 * i;
+            const double x = R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0];
+            const double y = R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1];
+            const double z = R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2];
+            double chi2 = 1e30;
+            if (z > 0) {
+                const double ex = obs[2 * i] - (c.fx * x / z + c.cx), ey = obs[2 * i + 1] - (c.fy * y / z + c.cy);
+                chi2 = inv_sigma2[i] * (ex * ex + ey * ey);
+            }
+            inlier[i] = chi2 <= chi2_th;
+            n_in += inlier[i];
+        }
+        if (n_in < 3) return -3;
+    }
+    return n_in;
+}
+
+bool sst_triangulate(const sst_camera &c, const double x1[2], const double x2[2], const double R1[9], const double t1[3],
+                     const double R2[9], const double t2[3], double sigma2_1, double sigma2_2, double X[3])
+{
+    if (!triangulate_dlt(c, x1, x2, R1, t1, R2, t2, X)) return false;
+    const double a[3] = {R1[0] * X[0] + R1[1] * X[1] + R1[2] * X[2] + t1[0], R1[3] * X[0] + R1[4] * X[1] + R1[5] * X[2] + t1[1],
+                         R1[6] * X[0] + R1[7] * X[1] + R1[8] * X[2] + t1[2]};
+    const double b[3] = {R2[0] * X[0] + R2[1] * X[1] + R2[2] * X[2] + t2[0], R2[3] * X[0] + R2[4] * X[1] + R2[5] * X[2] + t2[1],
+                         R2[6] * X[0] + R2[7] * X[1] + R2[8] * X[2] + t2[2]};
+    if (a[2] <= 0 || b[2] <= 0) return false;
+    const double e1x = c.fx * a[0] / a[2] + c.cx - x1[0], e1y = c.fy * a[1] / a[2] + c.cy - x1[1];
+    if (e1x * e1x + e1y * e1y > 5.991 * sigma2_1) return false;
+    const double e2x = c.fx * b[0] / b[2] + c.cx - x2[0], e2y = c.fy * b[1] / b[2] + c.cy - x2[1];
+    if (e2x * e2x + e2y * e2y > 5.991 * sigma2_2) return false;
+    /* parallax between the two viewing rays (in world coordinates) */
+    const double O1[3] = {-(R1[0] * t1[0] + R1[3] * t1[1] + R1[6] * t1[2]), -(R1[1] * t1[0] + R1[4] * t1[1] + R1[7] * t1[2]),
+                          -(R1[2] * t1[0] + R1[5] * t1[1] + R1[8] * t1[2])};
+    const double O2[3] = {-(R2[0] * t2[0] + R2[3] * t2[1] + R2[6] * t2[2]), -(R2[1] * t2[0] + R2[4] * t2[1] + R2[7] * t2[2]),
+                          -(R2[2] * t2[0] + R2[5] * t2[1] + R2[8] * t2[2])};
+    const double r1[3] = {X[0] - O1[0], X[1] - O1[1], X[2] - O1[2]}, r2[3] = {X[0] - O2[0], X[1] - O2[1], X[2] - O2[2]};
+    const double d1 = std::sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]), d2 = std::sqrt(r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2]);
+    const double cp = (r1[0] * r2[0] + r1[1] * r2[1] + r1[2] * r2[2]) / (d1 * d2);
+    return cp < 0.9998;
+}
+
+/* Robust cost and, optionally, the Schur-reduced normal equations of the two-view problem. */
+namespace {
+
+struct ba_problem {
+    int n;
+    const double *obs1, *obs2, *w1, *w2;
+    sst_camera c;
+};
+
+inline bool inv3(const double *m, double *o)
+{
+    const double d = det3(m);
+    if (!(std::fabs(d) > 1e-300)) return false;
+    const double id = 1.0 / d;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+/* one observation: residual e (2), d e / d Y (2x3, as rows a and b), Huber weight; false if behind the camera */
+inline bool ba_residual(const sst_camera &c, const double Y[3], const double *obs, double w0, double e[2], double a[3], double b[3],
+                        double &w, double &rho)
+{
+    if (Y[2] <= 0) return false;
+    const double iz = 1.0 / Y[2], iz2 = iz * iz;
+    e[0] = obs[0] - (c.fx * Y[0] * iz + c.cx);
+    e[1] = obs[1] - (c.fy * Y[1] * iz + c.cy);
+    a[0] = -c.fx * iz; a[1] = 0; a[2] = c.fx * Y[0] * iz2;
+    b[0] = 0; b[1] = -c.fy * iz; b[2] = c.fy * Y[1] * iz2;
+    const double e2 = w0 * (e[0] * e[0] + e[1] * e[1]), d2 = 5.991;
+    if (e2 > d2) { const double se = std::sqrt(e2), dl = std::sqrt(d2); w = w0 * dl / se; rho = 2 * dl * se - d2; }
+    else { w = w0; rho = e2; }
+    return true;
+}
+
+double ba_cost(const ba_problem &pb, const double R[9], const double t[3], const double *X)
+{
+    double cost = 0;
+    for (int i = 0; i < pb.n; i++) {
+        const double *P = X + 3 * i;
+        const double Y2[3] = {R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0], R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1],
+                              R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2]};
+        double e[2], a[3], b[3], w, rho;
+        cost += ba_residual(pb.c, P, pb.obs1 + 2 * i, pb.w1[i], e, a, b, w, rho) ? rho : 1e6;
+        cost += ba_residual(pb.c, Y2, pb.obs2 + 2 * i, pb.w2[i], e, a, b, w, rho) ? rho : 1e6;
+    }
+    return cost;
+}
+
+} // namespace
+
+int sst_two_view_ba(const sst_camera &c, int n, const double *obs1, const double *obs2, const double *w1, const double *w2,
+                    double R[9], double t[3], double *X, int iterations)
+{
+    if (n < 6) return 0;
+    const ba_problem pb{n, obs1, obs2, w1, w2, c};
+    std::vector<double> Hll((size_t)9 * n), Hpl((size_t)18 * n), bl((size_t)3 * n), Xn((size_t)3 * n), dl((size_t)3 * n);
+    double lambda = -1, cost = ba_cost(pb, R, t, X);
+    int accepted = 0;
+    for (int it = 0; it < iterations; it++) {
+        double Hpp[36] = {0}, bp[6] = {0};
+        for (int i = 0; i < n; i++) {
+            const double *P = X + 3 * i;
+            double *hl = &Hll[9 * i], *hp = &Hpl[18 * i], *g = &bl[3 * i];
+            for (int k = 0; k < 9; k++) hl[k] = 0;
+            for (int k = 0; k < 18; k++) hp[k] = 0;
+            g[0] = g[1] = g[2] = 0;
+            double e[2], a[3], b[3], w, rho;
+            if (ba_residual(c, P, obs1 + 2 * i, w1[i], e, a, b, w, rho)) { /* camera 1: identity pose, d Y / d X = I */
+                for (int r = 0; r < 3; r++) {
+                    g[r] -= w * (a[r] * e[0] + b[r] * e[1]);
+                    for (int q = 0; q < 3; q++) hl[3 * r + q] += w * (a[r] * a[q] + b[r] * b[q]);
+                }
+            }
+            const double Y[3] = {R[0] * P[0] + R[1] * P[1] + R[2] * P[2] + t[0], R[3] * P[0] + R[4] * P[1] + R[5] * P[2] + t[1],
+                                 R[6] * P[0] + R[7] * P[1] + R[8] * P[2] + t[2]};
+            if (ba_residual(c, Y, obs2 + 2 * i, w2[i], e, a, b, w, rho)) {
+                /* d e / d X = (d e / d Y) R ; d e / d xi = (d e / d Y) [-[Y]x, I] */
+                double ax[3], bx[3], aj[6], bj[6];
+                for (int q = 0; q < 3; q++) {
+                    ax[q] = a[0] * R[q] + a[1] * R[3 + q] + a[2] * R[6 + q];
+                    bx[q] = b[0] * R[q] + b[1] * R[3 + q] + b[2] * R[6 + q];
+                }
+                aj[0] = a[2] * Y[1] - a[1] * Y[2]; aj[1] = a[0] * Y[2] - a[2] * Y[0]; aj[2] = a[1] * Y[0] - a[0] * Y[1];
+                bj[0] = b[2] * Y[1] - b[1] * Y[2]; bj[1] = b[0] * Y[2] - b[2] * Y[0]; bj[2] = b[1] * Y[0] - b[0] * Y[1];
+                for (int q = 0; q < 3; q++) { aj[3 + q] = a[q]; bj[3 + q] = b[q]; }
+                for (int r = 0; r < 3; r++) {
+                    g[r] -= w * (ax[r] * e[0] + bx[r] * e[1]);
+                    for (int q = 0; q < 3; q++) hl[3 * r + q] += w * (ax[r] * ax[q] + bx[r] * bx[q]);
+                }
+                for (int r = 0; r < 6; r++) {
+                    bp[r] -= w * (aj[r] * e[0] + bj[r] * e[1]);
+                    for (int q = 0; q < 6; q++) Hpp[6 * r + q] += w * (aj[r] * aj[q] + bj[r] * bj[q]);
+                    for (int q = 0; q < 3; q++) hp[3 * r + q] += w * (aj[r] * ax[q] + bj[r] * bx[q]);
+                }
+            }
+        }
+        if (lambda < 0) {
+            double mx = 0;
+            for (int r = 0; r < 6; r++) mx = std::max(mx, Hpp[7 * r]);
+            for (int i = 0; i < n; i++)
+                for (int r = 0; r < 3; r++) mx = std::max(mx, Hll[9 * i + 4 * r]);
+            lambda = 1e-5 * mx;
+        }
+        /* Schur complement on the pose block */
+        double S[36], g6[6];
+        for (int k = 0; k < 36; k++) S[k] = Hpp[k];
+        for (int r = 0; r < 6; r++) { S[7 * r] += lambda; g6[r] = bp[r]; }
+        bool ok = true;
+        std::vector<double> Hinv((size_t)9 * n);
+        for (int i = 0; i < n && ok; i++) {
+            double m[9];
+            for (int k = 0; k < 9; k++) m[k] = Hll[9 * i + k];
+            m[0] += lambda; m[4] += lambda; m[8] += lambda;
+            ok = inv3(m, &Hinv[9 * i]);
+            if (!ok) break;
+            const double *hp = &Hpl[18 * i], *hi = &Hinv[9 * i], *g = &bl[3 * i];
+            double T[18]; /* Hpl * Hll^-1, 6x3 */
+            for (int r = 0; r < 6; r++)
+                for (int q = 0; q < 3; q++) T[3 * r + q] = hp[3 * r] * hi[q] + hp[3 * r + 1] * hi[3 + q] + hp[3 * r + 2] * hi[6 + q];
+            for (int r = 0; r < 6; r++) {
+                g6[r] -= T[3 * r] * g[0] + T[3 * r + 1] * g[1] + T[3 * r + 2] * g[2];
+                for (int q = 0; q < 6; q++) S[6 * r + q] -= T[3 * r] * hp[3 * q] + T[3 * r + 1] * hp[3 * q + 1] + T[3 * r + 2] * hp[3 * q + 2];
+            }
+        }
+        if (ok) ok = chol6_solve(S, g6);
+        double Rn[9], tn[3], new_cost = 0;
+        if (ok) {
+            for (int i = 0; i < n; i++) {
+                const double *hp = &Hpl[18 * i], *hi = &Hinv[9 * i], *g = &bl[3 * i];
+                double r3[3];
+                for (int q = 0; q < 3; q++) {
+                    double v = g[q];
+                    for (int r = 0; r < 6; r++) v -= hp[3 * r + q] * g6[r];
+                    r3[q] = v;
+                }
+                for (int q = 0; q < 3; q++) {
+                    dl[3 * i + q] = hi[3 * q] * r3[0] + hi[3 * q + 1] * r3[1] + hi[3 * q + 2] * r3[2];
+                    Xn[3 * i + q] = X[3 * i + q] + dl[3 * i + q];
+                }
+            }
+            double dR[9], dt[3];
+            se3_exp(g6, dR, dt);
+            mat3_mul(dR, R, Rn);
+            for (int r = 0; r < 3; r++) tn[r] = dR[3 * r] * t[0] + dR[3 * r + 1] * t[1] + dR[3 * r + 2] * t[2] + dt[r];
+            new_cost = ba_cost(pb, Rn, tn, Xn.data());
+        }
+        if (ok && new_cost < cost) {
+            memcpy(R, Rn, sizeof(Rn));
+            memcpy(t, tn, sizeof(tn));
+            memcpy(X, Xn.data(), sizeof(double) * 3 * (size_t)n);
+            cost = new_cost;
+            lambda = std::max(lambda / 3.0, 1e-12);
+            accepted++;
+        } else {
+            lambda *= 4.0;
+        }
+    }
+    return accepted;
+}
+
+void sst_pose_to_twc(const double R[9], const double t[3], double pos[3], double q[4])
+{
+    double Rwc[9];
+    mat3_t(R, Rwc);
+    for (int i = 0; i < 3; i++) pos[i] = -(Rwc[3 * i] * t[0] + Rwc[3 * i + 1] * t[1] + Rwc[3 * i + 2] * t[2]);
+    /* Eigen::Quaternion(Matrix3): trace branch, else the largest diagonal element */
+    const double tr = Rwc[0] + Rwc[4] + Rwc[8];
+    double x, y, z, w;
+    if (tr > 0) {
+        double s = std::sqrt(tr + 1.0);
+        w = 0.5 * s;
+        s = 0.5 / s;
+        x = (Rwc[7] - Rwc[5]) * s; y = (Rwc[2] - Rwc[6]) * s; z = (Rwc[3] - Rwc[1]) * s;
+    } else {
+        int i = 0;
+        if (Rwc[4] > Rwc[0]) i = 1;
+        if (Rwc[8] > Rwc[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double s = std::sqrt(Rwc[4 * i] - Rwc[4 * j] - Rwc[4 * k] + 1.0);
+        double v[3];
+        v[i] = 0.5 * s;
+        s = 0.5 / s;
+        w = (Rwc[3 * k + j] - Rwc[3 * j + k]) * s;
+        v[j] = (Rwc[3 * j + i] + Rwc[3 * i + j]) * s;
+        v[k] = (Rwc[3 * k + i] + Rwc[3 * i + k]) * s;
+        x = v[0]; y = v[1]; z = v[2];
+    }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * frame-to-frame state machine (ss_track.h)
+ * ------------------------------------------------------------------------------------------- */
+void sst_tracker::reset()
+{
+    state = 0;
+    have_ref = false;
+    have_vel = false;
+    pose_hist.clear();
+    ref = sst_frame();
+    prev = sst_frame();
+}
+
+int sst_tracker::want_match() const
+{
+    if (state == 2) return SST_MATCH_PREV;
+    if (state == 1 && have_ref) return SST_MATCH_REF;
+    return SST_MATCH_NONE;
+}
+
+int sst_tracker::n_train() const
+{
+    const int w = want_match();
+    return w == SST_MATCH_PREV ? prev.n : w == SST_MATCH_REF ? ref.n : 0;
+}
+
+namespace {
+
+/* one query per train row: the smallest distance wins, ties to the lowest query index */
+void unique_matches(int n, int n_train, const int32_t *idx, const uint16_t *d1, std::vector<int32_t> &m)
+{
+    m.assign((size_t)n, -1);
+    std::vector<int32_t> owner((size_t)n_train, -1);
+    for (int i = 0; i < n; i++) {
+        const int j = idx[i];
+        if (j < 0 || j >= n_train) continue;
+        if (owner[j] < 0 || d1[i] < d1[owner[j]]) owner[j] = i;
+    }
+    for (int j = 0; j < n_train; j++)
+        if (owner[j] >= 0) m[owner[j]] = j;
+}
+
+} // namespace
+
+int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32_t *match_idx, const uint16_t *d1, sst_pose_out &out)
+{
+    sst_frame cur;
+    cur.n = n;
+    cur.und.resize((size_t)2 * n);
+    sst_undistort(cam, n, xy, cur.und.data());
+    cur.octave.assign(octave, octave + n);
+    cur.has3d.assign((size_t)n, 0);
+    cur.p3d.assign((size_t)3 * n, 0.0);
+    out = sst_pose_out();
+
+    const int want = want_match();
+    std::vector<int32_t> m;
+    if (want != SST_MATCH_NONE) {
+        unique_matches(n, n_train(), match_idx, d1, m);
+        for (int i = 0; i < n; i++) out.n_matches += m[i] >= 0;
+    }
+
+    if (want == SST_MATCH_NONE) { /* NO_IMAGES_YET, LOST, or NOT_INITIALIZED without a reference */
+        state = 1;
+        have_ref = n > 100;
+        if (have_ref) ref = cur;
+        out.state = state;
+        return have_ref ? SST_KEEP_AS_REF : SST_KEEP_NONE;
+    }
+
+    if (want == SST_MATCH_REF) {
+        out.state = 1;
+        /* SearchForInitialization looks for the match inside a 100-px window around the reference
+         * keypoint: gate the all-pairs matches the same way */
+        for (int i = 0; i < n; i++)
+            if (m[i] >= 0 && !(std::fabs(cur.und[2 * i] - ref.und[2 * m[i]]) < 100.0 && std::fabs(cur.und[2 * i + 1] - ref.und[2 * m[i] + 1]) < 100.0)) {
+                m[i] = -1;
+                out.n_matches--;
+            }
+        if (n <= 100 || out.n_matches < 100) { /* MonocularInitialization: drop the reference */
+            have_ref = false;
+            return SST_KEEP_NONE;
+        }
+        std::vector<double> x1, x2;
+        std::vector<int> qi;
+        for (int i = 0; i < n; i++)
+            if (m[i] >= 0) {
+                x1.push_back(ref.und[2 * m[i]]); x1.push_back(ref.und[2 * m[i] + 1]);
+                x2.push_back(cur.und[2 * i]); x2.push_back(cur.und[2 * i + 1]);
+                qi.push_back(i);
+            }
+        double R[9], t[3];
+        std::vector<uint8_t> tri;
+        std::vector<double> p3d;
+        const int n_tri = sst_two_view(cam, (int)qi.size(), x1.data(), x2.data(), R, t, tri, p3d);
+        if (n_tri <= 0) return SST_KEEP_NONE; /* keep the reference, try the next frame */
+        { /* Optimizer::GlobalBundleAdjustemnt(map, 20) of CreateInitialMapMonocular, on the two views */
+            std::vector<double> o1, o2, w1, w2, X;
+            std::vector<size_t> ks;
+            for (size_t k = 0; k < qi.size(); k++)
+                if (tri[k]) {
+                    o1.push_back(x1[2 * k]); o1.push_back(x1[2 * k + 1]);
+                    o2.push_back(x2[2 * k]); o2.push_back(x2[2 * k + 1]);
+                    w1.push_back(1.0 / std::pow(scale_factor, 2.0 * ref.octave[m[qi[k]]]));
+                    w2.push_back(1.0 / std::pow(scale_factor, 2.0 * cur.octave[qi[k]]));
+                    for (int a = 0; a < 3; a++) X.push_back(p3d[3 * k + a]);
+                    ks.push_back(k);
+                }
+            sst_two_view_ba(cam, (int)ks.size(), o1.data(), o2.data(), w1.data(), w2.data(), R, t, X.data(), 20);
+            for (size_t j = 0; j < ks.size(); j++)
+                for (int a = 0; a < 3; a++) p3d[3 * ks[j] + a] = X[3 * j + a];
+        }
+        std::vector<double> depths;
+        for (size_t k = 0; k < qi.size(); k++)
+            if (tri[k]) depths.push_back(p3d[3 * k + 2]);
+        std::sort(depths.begin(), depths.end());
+        const double median = depths[(depths.size() - 1) / 2];
+        if (!(median > 0)) { have_ref = false; return SST_KEEP_NONE; }
+        const double inv = 1.0 / median;
+        memcpy(cur.R, R, sizeof(R));
+        for (int k = 0; k < 3; k++) cur.t[k] = t[k] * inv;
+        for (size_t k = 0; k < qi.size(); k++)
+            if (tri[k]) {
+                cur.has3d[qi[k]] = 1;
+                for (int a = 0; a < 3; a++) cur.p3d[3 * qi[k] + a] = p3d[3 * k + a] * inv;
+            }
+        state = 2;
+        have_ref = false;
+        have_vel = false;
+        pose_hist.assign(cur.R, cur.R + 9);
+        pose_hist.insert(pose_hist.end(), cur.t, cur.t + 3);
+        prev = cur;
+        out.state = 2;
+        out.n_inliers = n_tri;
+        out.n_map_points = n_tri;
+        sst_pose_to_twc(cur.R, cur.t, out.pos, out.quat);
+        return SST_KEEP_AS_PREV;
+    }
+
+    /* state OK: pose-only optimisation on the points carried by the previous frame */
+    /* predicted pose: constant velocity when there is one (TrackWithMotionModel), else the last pose */
+    if (have_vel) {
+        mat3_mul(vel_R, prev.R, cur.R);
+        for (int r = 0; r < 3; r++) cur.t[r] = vel_R[3 * r] * prev.t[0] + vel_R[3 * r + 1] * prev.t[1] + vel_R[3 * r + 2] * prev.t[2] + vel_t[r];
+    } else {
+        memcpy(cur.R, prev.R, sizeof(prev.R));
+        memcpy(cur.t, prev.t, sizeof(prev.t));
+    }
+    /* SearchByProjection accepts a map point only within th * scale^octave px of its projection under
+     * the predicted pose (th = 15 for monocular, doubled once if fewer than 20 points pass) */
+    std::vector<double> P, obs, w;
+    std::vector<int> qi;
+    for (double th = 15.0; th <= 30.0; th *= 2.0) {
+        P.clear(); obs.clear(); w.clear(); qi.clear();
+        for (int i = 0; i < n; i++) {
+            if (m[i] < 0 || !prev.has3d[m[i]]) continue;
+            const double *Q = &prev.p3d[3 * m[i]];
+            const double x = cur.R[0] * Q[0] + cur.R[1] * Q[1] + cur.R[2] * Q[2] + cur.t[0];
+            const double y = cur.R[3] * Q[0] + cur.R[4] * Q[1] + cur.R[5] * Q[2] + cur.t[1];
+            const double z = cur.R[6] * Q[0] + cur.R[7] * Q[1] + cur.R[8] * Q[2] + cur.t[2];
+            if (z <= 0) continue;
+            const double r = th * std::pow(scale_factor, (double)cur.octave[i]);
+            if (!(std::fabs(cam.fx * x / z + cam.cx - cur.und[2 * i]) < r && std::fabs(cam.fy * y / z + cam.cy - cur.und[2 * i + 1]) < r)) continue;
+            for (int a = 0; a < 3; a++) P.push_back(Q[a]);
+            obs.push_back(cur.und[2 * i]); obs.push_back(cur.und[2 * i + 1]);
+            w.push_back(1.0 / std::pow(scale_factor, 2.0 * cur.octave[i]));
+            qi.push_back(i);
+        }
+        if (qi.size() >= 20) break;
+    }
+    std::vector<uint8_t> inl;
+    const int n_in = sst_pose_only((int)qi.size(), P.data(), obs.data(), w.data(), cam, cur.R, cur.t, inl);
+    out.n_inliers = n_in > 0 ? n_in : 0;
+    if (n_in < 30) {
+        state = 4;
+        out.state = 4;
+        prev = sst_frame();
+        have_vel = false;
+        return SST_KEEP_NONE;
+    }
+    for (size_t k = 0; k < qi.size(); k++)
+        if (inl[k]) {
+            cur.has3d[qi[k]] = 1;
+            for (int a = 0; a < 3; a++) cur.p3d[3 * qi[k] + a] = P[3 * k + a];
+        }
+    /* New points from matches that carry none yet.  A track is triangulated between its FIRST
+     * observation (the anchor) and this one, so the baseline grows until the parallax test passes --
+     * the role keyframes play in LocalMapping::CreateNewMapPoints. */
+    if (prev.anchor.empty()) prev.anchor.assign((size_t)prev.n, -1);
+    cur.anchor.assign((size_t)n, -1);
+    cur.anchor_xy.assign((size_t)2 * n, 0.0);
+    cur.anchor_sigma2.assign((size_t)n, 1.0);
+    const int prev_pose_id = (int)(pose_hist.size() / 12) - 1; /* pose of prev, pushed when it was tracked */
+    for (int i = 0; i < n; i++) {
+        const int j = m[i];
+        if (j < 0 || prev.has3d[j]) continue;
+        int a_pose;
+        double a_xy[2], a_s2;
+        if (prev.anchor[j] >= 0) {
+            a_pose = prev.anchor[j];
+            a_xy[0] = prev.anchor_xy[2 * j]; a_xy[1] = prev.anchor_xy[2 * j + 1];
+            a_s2 = prev.anchor_sigma2[j];
+        } else {
+            a_pose = prev_pose_id;
+            a_xy[0] = prev.und[2 * j]; a_xy[1] = prev.und[2 * j + 1];
+            a_s2 = std::pow(scale_factor, 2.0 * prev.octave[j]);
+        }
+        double X[3];
+        const double s2 = std::pow(scale_factor, 2.0 * cur.octave[i]);
+        const double *aR = &pose_hist[(size_t)12 * a_pose], *at = aR + 9;
+        if (sst_triangulate(cam, a_xy, &cur.und[2 * i], aR, at, cur.R, cur.t, a_s2, s2, X)) {
+            cur.has3d[i] = 1;
+            for (int a = 0; a < 3; a++) cur.p3d[3 * i + a] = X[a];
+        } else {
+            cur.anchor[i] = a_pose;
+            cur.anchor_xy[2 * i] = a_xy[0]; cur.anchor_xy[2 * i + 1] = a_xy[1];
+            cur.anchor_sigma2[i] = a_s2;
+        }
+    }
+    pose_hist.insert(pose_hist.end(), cur.R, cur.R + 9);
+    pose_hist.insert(pose_hist.end(), cur.t, cur.t + 3);
+    for (int i = 0; i < n; i++) out.n_map_points += cur.has3d[i];
+    { /* mVelocity = Tcw * Twc_last */
+        double Rpt[9];
+        mat3_t(prev.R, Rpt);
+        mat3_mul(cur.R, Rpt, vel_R);
+        for (int r = 0; r < 3; r++) vel_t[r] = cur.t[r] - (vel_R[3 * r] * prev.t[0] + vel_R[3 * r + 1] * prev.t[1] + vel_R[3 * r + 2] * prev.t[2]);
+        have_vel = true;
+    }
+    prev = cur;
+    out.state = 2;
+    sst_pose_to_twc(cur.R, cur.t, out.pos, out.quat);
+    return SST_KEEP_AS_PREV;
+}

@@ -14,12 +14,11 @@
  *   main: env, connect, framing, guards     :341-627           -> main
  *   cv::imdecode(IMREAD_UNCHANGED) on PNM   :546               -> decode_pnm (P5 -> 1 channel,
  *                                                                 P6 -> 3 channels in BGR order)
- *   TrackMonocular                          :594               -> ss_extract + ss_match against
- *                                                                 the previous frame
+ *   TrackMonocular                          :594               -> ss_track (HIP extraction + HIP
+ *                                                                 match + host geometry; a bounded
+ *                                                                 monocular front-end)
  *   SendPosePacket                          :225-282           -> send_pose_packet (emitted only
- *                                                                 when tracking_state == OK, :596;
- *                                                                 pose estimation itself is the
- *                                                                 next step)
+ *                                                                 when tracking_state == OK, :596)
  *   pacing sleep, timing summary            :618-624, :656-664 -> same
  *
  * Extras, all off by default so the binary stays a strict drop-in:
@@ -309,8 +308,6 @@ int main(int argc, char **argv)
     ss_ctx *ctx = nullptr;
     vector<float> vTimesTrack;
     double previousTimestamp = -1.0;
-    vector<uint8_t> prevDesc;
-    int prevN = 0;
 
     cout << endl << "-------" << endl;
     cout << "Connecting to tcp://127.0.0.1:" << port << " ..." << endl;
@@ -433,7 +430,6 @@ int main(int argc, char **argv)
             calibrationReceived = true;
             vTimesTrack.clear();
             previousTimestamp = -1.0;
-            prevN = 0;
             cout << "Calibration parameters received. SLAM system ready to process frames." << endl;
             continue;
         }
@@ -466,42 +462,30 @@ int main(int argc, char **argv)
             }
 
             const auto t1 = chrono::steady_clock::now();
-            ss_frame_result res{};
-            int trackingState = NOT_INITIALIZED;
-            int nMatches = 0;
-            const int rc = ss_extract(ctx, packet.camera_id, pix.data(), w, h, ch, w * ch, packet.timestamp, &res);
+            /* TrackMonocular :594 -> Twc + tracking state :596 */
+            ss_pose tracked{};
+            const int rc = ss_track(ctx, packet.camera_id, pix.data(), w, h, ch, w * ch, packet.timestamp, &tracked);
             if (rc != SS_OK) {
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl; /* bad frame => log + skip */
                 continue;
             }
-            vector<uint8_t> curDesc(res.descriptors, res.descriptors + (size_t)res.n_keypoints * SS_DESC_BYTES);
-            if (prevN > 0 && res.n_keypoints > 0) {
-                vector<int32_t> idx((size_t)res.n_keypoints);
-                vector<uint16_t> d1((size_t)res.n_keypoints), d2((size_t)res.n_keypoints);
-                if (ss_match(ctx, curDesc.data(), res.n_keypoints, prevDesc.data(), prevN, 50, 9, 10, 0, idx.data(),
-                             d1.data(), d2.data()) == SS_OK)
-                    for (int32_t v : idx) nMatches += v >= 0;
-                else
-                    cerr << "Match skipped: " << ss_last_error(ctx) << endl;
-            }
-            prevDesc.swap(curDesc);
-            prevN = res.n_keypoints;
-            /* Pose estimation from the matches (two-view initialisation, PnP) is not built yet
-             * (DESIGN.md "next"): the state never reaches OK, so, like the reference while it is
-             * initialising, no pose packet is sent (:596). */
-            if (trackingState == TRACKING_OK) {
-                const pose T{0, 0, 0, 0, 0, 0, 1};
+            const int trackingState = tracked.tracking_state;
+            if (trackingState == TRACKING_OK) { /* :596: a pose is shipped only while tracking is OK */
+                const pose T{tracked.position[0], tracked.position[1], tracked.position[2], tracked.quaternion[0],
+                             tracked.quaternion[1], tracked.quaternion[2], tracked.quaternion[3]};
                 send_pose_packet(fd, T, packet.timestamp, packet.camera_id, trackingState);
             }
             if (emitFeatures) {
                 ssmp::packer pk;
-                pk.pack_map(6);
+                pk.pack_map(8);
                 pk.pack("type");           pk.pack("features");
                 pk.pack("timestamp");      pk.pack(packet.timestamp);
                 pk.pack("camera_id");      pk.pack(packet.camera_id);
                 pk.pack("tracking_state"); pk.pack(trackingState);
-                pk.pack("n_keypoints");    pk.pack((int)res.n_keypoints);
-                pk.pack("n_matches");      pk.pack(nMatches);
+                pk.pack("n_keypoints");    pk.pack((int)tracked.n_keypoints);
+                pk.pack("n_matches");      pk.pack((int)tracked.n_matches);
+                pk.pack("n_inliers");      pk.pack((int)tracked.n_inliers);
+                pk.pack("n_map_points");   pk.pack((int)tracked.n_map_points);
                 send_framed(fd, pk.buf);
             }
             const auto t2 = chrono::steady_clock::now();

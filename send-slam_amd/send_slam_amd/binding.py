@@ -15,7 +15,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
 SS_MAX_LEVELS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SS_OK = 0
 SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3, -4
@@ -23,7 +23,7 @@ SS_ERR_OVERFLOW, SS_ERR_NOT_CALIBRATED, SS_ERR_BAD_FRAME, SS_ERR_NO_MEMORY, SS_E
 
 EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy", "ss_last_error",
            "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_fetch_frame", "ss_match",
-           "ss_match_device", "ss_match_batch_device", "ss_synchronize", "ss_get_stream",
+           "ss_match_device", "ss_match_batch_device", "ss_track", "ss_track_reset", "ss_synchronize", "ss_get_stream",
            "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort"]
 
 
@@ -55,6 +55,12 @@ class BatchView(C.Structure):
 class StageStats(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("mean_ms", C.c_double), ("median_ms", C.c_double), ("algorithmic_bytes", C.c_int64)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("tracking_state", C.c_int32), ("camera_id", C.c_int32), ("timestamp", C.c_double),
+                ("position", C.c_double * 3), ("quaternion", C.c_double * 4), ("n_keypoints", C.c_int32),
+                ("n_matches", C.c_int32), ("n_inliers", C.c_int32), ("n_map_points", C.c_int32)]
 
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -108,6 +114,9 @@ def load():
     lib.ss_match_device.argtypes = lib.ss_match.argtypes
     lib.ss_match_batch_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+    lib.ss_track.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                             C.POINTER(Pose)]
+    lib.ss_track_reset.argtypes = [C.c_void_p]
     lib.ss_synchronize.argtypes = [C.c_void_p]
     lib.ss_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     lib.ss_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -196,6 +205,22 @@ class OrbContext:
                                        int(ratio_num), int(ratio_den), int(exclude_self), idx.ctypes.data,
                                        d1.ctypes.data, d2.ctypes.data))
         return idx, d1, d2
+
+    # ---- pose (bounded monocular front-end; needs set_calibration) ----
+    def track(self, img: np.ndarray, camera_id: int = 1, timestamp: float = 0.0) -> dict:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        po = Pose()
+        self._check(self._lib.ss_track(self._h, int(camera_id), img.ctypes.data, w, h, ch, w * ch, float(timestamp),
+                                       C.byref(po)))
+        return {"state": po.tracking_state, "camera_id": po.camera_id, "timestamp": po.timestamp,
+                "position": np.array(list(po.position)), "quaternion": np.array(list(po.quaternion)),
+                "n_keypoints": po.n_keypoints, "n_matches": po.n_matches, "n_inliers": po.n_inliers,
+                "n_map_points": po.n_map_points}
+
+    def track_reset(self):
+        self._check(self._lib.ss_track_reset(self._h))
 
     # ---- device in / device out (pointers are raw device addresses, e.g. tensor.data_ptr()) ----
     def extract_batch_device(self, d_ptr: int, n_frames: int, width: int, height: int, channels: int = 1,

@@ -98,6 +98,34 @@ def batch(seeds, width: int, height: int, t: int = 0) -> np.ndarray:
     return np.stack([frame(s, width, height, t) for s in seeds])
 
 
+PARALLAX_DISPARITIES = (2, 3, 4, 5, 6, 8)
+
+
+def parallax_frame(seed: int, width: int, height: int, t: int = 0, disparities=PARALLAX_DISPARITIES,
+                   sc: np.ndarray | None = None) -> np.ndarray:
+    """Frame t of a sideways-translating camera in front of a staircase of fronto-parallel strips.
+
+    The image is cut into len(disparities) horizontal bands; band b shows the seed's scene shifted by
+    disparities[b] * t px in +x, i.e. a rigid scene whose band b lies at depth f * B / disparities[b]
+    seen by a pinhole camera that has moved t * B along -x (no rotation).  It gives the pose stage
+    (ss_track) a sequence with real parallax and a known answer: translation along one axis, band depths
+    in the ratio 1 / disparity.  max(disparities) * t must stay below the canvas margin (256 px).
+    """
+    if max(disparities) * t >= _MARGIN or t < 0:
+        raise ValueError("parallax sequence runs off the canvas")
+    if sc is None:
+        sc = scene(seed, width, height)
+    out = np.empty((height, width), np.int64)
+    nb = len(disparities)
+    for b, d in enumerate(disparities):
+        y0, y1 = height * b // nb, height * (b + 1) // nb
+        ox = _MARGIN - d * t
+        out[y0:y1] = sc[_MARGIN + y0:_MARGIN + y1, ox:ox + width]
+    nrng = np.random.Generator(np.random.PCG64([seed, t, 0x9A7A]))
+    noise = nrng.integers(-3, 4, size=(height, width), dtype=np.int64)
+    return np.ascontiguousarray(np.clip(out + noise, 0, 255).astype(np.uint8))
+
+
 def color_frame(seed: int, width: int, height: int, t: int = 0) -> np.ndarray:
     """(height, width, 3) uint8: three decorrelated planes of the same scene geometry."""
     g = frame(seed, width, height, t).astype(np.int64)

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sendslam_orb.h but not exported"
     assert sorted(binding.EXPORTS) == names
-    assert lib.ss_abi_version() == 1
+    assert lib.ss_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -38,6 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(binding.Camera) == 16 + 8 * 8 + 8 + 8 + 8 + 24
     assert binding.KP_DTYPE.itemsize == 24
     assert C.sizeof(binding.StageStats) == 32 + 8 + 24 + 8
+    assert C.sizeof(binding.Pose) == 8 + 8 + 24 + 32 + 16
     p = binding.default_params()
     # reference YAML literals, orbslam3_mono_networked.cc:193-206
     assert (p.n_features, p.n_levels, p.ini_th_fast, p.min_th_fast, p.max_batch) == (1250, 8, 20, 7, 1)

@@ -124,6 +124,21 @@ def test_colour_input_uses_calibration_rgb_flag(oracle):
         assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
 
 
+def test_four_channel_input_ignores_alpha(oracle):
+    """RGBA / BGRA frames: GrabImageMonocular uses RGBA2GRAY / BGRA2GRAY, the same weights, alpha unused."""
+    col = synth.color_frame(12, 320, 240)
+    rgba = np.concatenate([col, np.random.default_rng(0).integers(0, 256, (240, 320, 1), dtype=np.uint8)], axis=2)
+    cam = binding.Camera(type=b"PinHole", fx=500, fy=500, cx=160, cy=120, width=320, height=240, fps=30, rgb=1,
+                         th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+    with binding.OrbContext(0, n_features=400) as ctx:
+        ctx.set_calibration(1, cam)
+        k4, d4, _ = ctx.extract(rgba)
+        k3, d3, _ = ctx.extract(col)
+    assert k4.tobytes() == k3.tobytes() and np.array_equal(d4, d3)
+    okps, odesc, _ = oracle.extract(oracle.gray(np.ascontiguousarray(rgba), 1), oracle.default_params(n_features=400))
+    assert k4.tobytes() == okps.tobytes() and np.array_equal(d4, odesc)
+
+
 def test_errors_leave_the_context_usable(oracle):
     img = synth.frame(11, 320, 240)
     with binding.OrbContext(0, n_features=300) as ctx:
@@ -380,6 +395,49 @@ def test_downstream_pnp_pose_from_hip_outputs(oracle):
     # the pair is the same scene shifted by (+3, -2) px: t = (3 Z / fx, -2 Z / fy, 0), R = I
     assert np.abs(t_h - np.array([3 * Z / fx, -2 * Z / fy, 0.0])).max() < 5e-3  # keypoints are integer pixels x scale
     assert np.abs(R_h - np.eye(3)).max() < 2e-3
+
+
+def test_ss_track_poses_vs_oracle_pipeline_and_truth(oracle):
+    """ss_track through the C ABI (HIP extraction + HIP match + host geometry) against the all-CPU
+    statement of the same pipeline (C oracle extraction + match, oracle/vo_oracle.py tracker) on a
+    parallax sequence, including a lost frame and the re-initialisation after it.  Features and matches
+    are bit-identical, so poses differ by the eigen-solver only: tolerance 1e-6 absolute on a
+    unit-median-depth map (north star: 1e-4 rel)."""
+    from oracle import vo_oracle as vo
+    w, h, seed, nf = 640, 480, 77, 1000
+    sc = synth.scene(seed, w, h)
+    frames = [synth.parallax_frame(seed, w, h, t, sc=sc) for t in range(9)]
+    frames.insert(6, np.full((h, w), 90, np.uint8))  # a featureless frame: tracking is lost, then restarts
+    cam = binding.Camera(type=b"PinHole", fx=500, fy=500, cx=320, cy=240, k1=-0.05, k2=0.01, p1=1e-4, p2=-1e-4,
+                         width=w, height=h, fps=30, rgb=1, th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+    ocam = vo.Camera(500, 500, 320, 240, -0.05, 0.01, 1e-4, -1e-4)
+    import track_ref
+    want = track_ref.run(oracle, frames, ocam, nf)
+    got = []
+    with binding.OrbContext(0, n_features=nf) as ctx:
+        with pytest.raises(binding.OrbError) as e:
+            ctx.track(frames[0])
+        assert e.value.code == binding.SS_ERR_NOT_CALIBRATED
+        ctx.set_calibration(1, cam)
+        for t, img in enumerate(frames):
+            got.append(ctx.track(img, 1, t / 30.0))
+        ctx.track_reset()
+        assert ctx.track(frames[0])["state"] == 1
+    states = [g["state"] for g in got]
+    assert states[:2] == [1, 1] and states[6] == 4 and states[7] == 1 and states[-1] == 2 and states.count(2) >= 5
+    for g, o in zip(got, want):
+        assert (g["state"], g["n_keypoints"], g["n_matches"], g["n_inliers"], g["n_map_points"]) == \
+               (o["state"], o["n_keypoints"], o["n_matches"], o["n_inliers"], o["n_map_points"])
+        assert np.allclose(g["position"], o["position"], rtol=0, atol=1e-6)
+        assert np.allclose(g["quaternion"], o["quaternion"], rtol=0, atol=1e-6)
+    assert [g["timestamp"] for g in got] == [t / 30.0 for t in range(len(frames))]
+    # truth for the first stretch: sliding along -x at constant speed, no rotation
+    ok = [t for t in range(6) if states[t] == 2]
+    pos = np.array([got[t]["position"] for t in ok])
+    v = pos[:, 0] / np.array(ok)
+    assert (v < 0).all() and np.abs(v / v.mean() - 1).max() < 0.08
+    assert np.abs(pos[:, 1:]).max() < 0.15 * np.abs(pos[:, 0]).max()
+    assert max(np.abs(got[t]["quaternion"][:3]).max() for t in ok) < 5e-3
 
 
 def test_contexts_do_not_leak_device_memory():

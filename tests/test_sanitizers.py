@@ -1,5 +1,5 @@
-"""CPU-only sanitizer runs (GPU AddressSanitizer is not available on the pool): the oracle and the
-front door's MessagePack decoder under ASan + UBSan."""
+"""CPU-only sanitizer runs (GPU AddressSanitizer is not available on the pool): the oracle, the
+front door's MessagePack decoder and the host geometry of ss_track under ASan + UBSan."""
 import os
 import subprocess
 import sys
@@ -14,6 +14,17 @@ def test_msgpack_decoder_fuzz_under_asan(tmp_path):
                            os.path.join(ROOT, "tests/native/msgpack_fuzz.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "decoded=" in out.stdout, out.stdout + out.stderr
+
+
+def test_track_geometry_under_asan_ubsan(tmp_path):
+    """40 frames of a synthetic sequence through sst_tracker: initialisation, two-view BA, tracking with
+    wrong matches, anchored triangulation, a lost frame and re-initialisation."""
+    exe = str(tmp_path / "track_asan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-o", exe, os.path.join(ROOT, "tests/native/track_asan.cpp"),
+                           os.path.join(ROOT, "send-slam_amd/csrc/ss_track.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "lost=1" in out.stdout, out.stdout + out.stderr[-3000:]
 
 
 def test_oracle_under_asan_ubsan(tmp_path):

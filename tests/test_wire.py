@@ -186,14 +186,21 @@ def test_frontdoor_without_gpu_fails_loudly_at_calibration(frontdoor):
 
 @pytest.mark.gpu
 def test_frontdoor_end_to_end_frames(frontdoor, oracle):
-    """Config 1 of BASELINE.json (plumbing): fake host <-> front door, calibration then frames;
-    every frame is extracted on the GPU; poses are sent only in state OK (none yet); the
-    optional 'features' message carries counts that equal the oracle's."""
-    w, h = 640, 480
-    frames = [synth.frame(40, w, h, t) for t in range(3)]
+    """Config 1 of BASELINE.json: fake host <-> front door, calibration then frames of a parallax
+    sequence.  Every frame goes through ss_track on the GPU; a pose packet is sent exactly for the
+    frames whose tracking state is OK (shim :596) and equals the all-CPU pipeline's pose; the optional
+    'features' message carries the counts of that pipeline."""
+    import track_ref
+    from oracle import vo_oracle as vo
+    w, h, seed = 640, 480, 77
+    sc = synth.scene(seed, w, h)
+    frames = [synth.parallax_frame(seed, w, h, t, sc=sc) for t in range(6)]
     col = synth.color_frame(41, w, h)
     host = FakeHost()
     b = run_backend(host, {"SENDSLAM_EMIT_FEATURES": "1"})
+    gray = lambda c: oracle.gray(np.ascontiguousarray(c), 1)  # PPM is R,G,B on the wire, a BGR Mat after decode, rgb: 1
+    want = track_ref.run(oracle, frames + [col], vo.Camera(500, 500, 320, 240), 1250, gray=gray)
+    n_expected = len(want) + sum(o["state"] == 2 for o in want)
     try:
         host.accept()
         dims = {"width": w, "height": h, "channels": 1}
@@ -202,29 +209,36 @@ def test_frontdoor_end_to_end_frames(frontdoor, oracle):
             host.send(wire.build_frame_packet(wire.encode_to_ppm(f), dims, camera_id=1, timestamp=1.0 + t / 30))
         host.send(wire.build_frame_packet(b"P6\n2 2\n255\n", dims, camera_id=1, timestamp=2.0))  # truncated -> skipped
         host.send(wire.build_frame_packet(wire.encode_to_ppm(col), dict(dims, channels=3), camera_id=1, timestamp=2.1))
-        msgs = host.recv_packets(4)
+        msgs = host.recv_packets(n_expected)
         host.send(wire.build_terminate_packet())
         rc = b.wait(timeout=60)
     finally:
         host.close()
     text = b.logs(200)[1]
     assert rc == 0, text
-    assert "Failed to decode frame image data." in text and "Frames processed: 4" in text
+    assert "Failed to decode frame image data." in text and "Frames processed: 7" in text
     assert "median tracking time:" in text and "mean tracking time:" in text
-    assert [m["type"] for m in msgs] == ["features"] * 4 and all(wire.handle_incoming_packet(msgpack.packb(m)) is None for m in msgs)
-    p = oracle.default_params()
-    prev = None
-    for m, f in zip(msgs[:3], frames):
-        kps, desc, _ = oracle.extract(f, p)
-        assert m["n_keypoints"] == len(kps) and m["camera_id"] == 1
-        if prev is not None:
-            idx, _, _ = oracle.match(desc, prev)
-            assert m["n_matches"] == int((idx >= 0).sum())
-        prev = desc
-    # colour frame: PPM is R,G,B on the wire, a BGR Mat after decode, weighed with rgb: 1
-    gray = oracle.gray(np.ascontiguousarray(col), 1)
-    kps, desc, _ = oracle.extract(gray, p)
-    assert msgs[3]["n_keypoints"] == len(kps)
+    stamps = [1.0 + t / 30 for t in range(6)] + [2.1]
+    k = 0
+    n_pose = 0
+    for o, ts in zip(want, stamps):
+        if o["state"] == 2:
+            m = msgs[k]
+            k += 1
+            n_pose += 1
+            pose = wire.handle_incoming_packet(msgpack.packb(m))  # what SlamHandler broadcasts on PoseRegistry
+            assert pose["type"] == "pose" and pose["camera_id"] == 1 and pose["tracking_state"] == 2
+            assert pose["timestamp"] == ts
+            got_p = np.array([pose["position"][a] for a in "xyz"])
+            got_q = np.array([pose["orientation"][a] for a in "xyzw"])
+            assert np.allclose(got_p, o["position"], rtol=0, atol=1e-6) and np.allclose(got_q, o["quaternion"], rtol=0, atol=1e-6)
+        m = msgs[k]
+        k += 1
+        assert m["type"] == "features" and wire.handle_incoming_packet(msgpack.packb(m)) is None  # ignored by the host
+        assert (m["tracking_state"], m["n_keypoints"], m["n_matches"], m["n_inliers"], m["n_map_points"]) == \
+               (o["state"], o["n_keypoints"], o["n_matches"], o["n_inliers"], o["n_map_points"]), (ts, m, o)
+    assert k == len(msgs) and n_pose >= 3
+    assert want[-1]["state"] == 4  # the unrelated colour frame loses tracking: no pose for it
 
 
 def test_docker_cli_shim_drives_the_frontdoor_like_dockerhandler(frontdoor, tmp_path):
