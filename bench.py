@@ -300,6 +300,28 @@ def main():
     lat = sorted(lat[2:])
     single_frame_ms = lat[len(lat) // 2] * 1e3
 
+    # Same boundary one step further (ss_track: extraction + match on the GPU, pose geometry on the
+    # host) on a parallax sequence, rank 0 only: per-frame time in tracking state OK.  Never `value`.
+    track_ms = track_ok = None
+    if rank == 0:
+        from send_slam_amd import synth
+        cam = binding.Camera(type=b"PinHole", fx=800.0, fy=800.0, cx=w / 2.0, cy=h / 2.0, width=w, height=h, fps=30.0,
+                             rgb=1, th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+        ctx.set_calibration(1, cam)
+        sc = synth.scene(1000, w, h)
+        tl, states = [], []
+        for t in range(14):
+            img = synth.parallax_frame(1000, w, h, t, sc=sc)
+            t1 = time.perf_counter()
+            po = ctx.track(img, 1, t / 30.0)
+            dt = time.perf_counter() - t1
+            states.append(po["state"])
+            if po["state"] == 2 and t > 0 and states[-2] == 2:
+                tl.append(dt)
+        if tl:
+            tl.sort()
+            track_ms, track_ok = tl[len(tl) // 2] * 1e3, states.count(2)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -359,6 +381,7 @@ def main():
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
         "roofline": roofline, "int_valu_roofline": int_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
         "single_frame_host_to_host_ms": round(single_frame_ms, 3),
+        "track_frame_host_to_host_ms": None if track_ms is None else round(track_ms, 3), "track_ok_frames_of_14": track_ok,
     }
     print(json.dumps(out))
     if world > 1:

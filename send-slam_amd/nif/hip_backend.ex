@@ -1,6 +1,6 @@
 defmodule SendSlam.HipNif do
   @moduledoc """
-  NIF stubs for libsendslam_orb.so (send-slam_amd/nif/sendslam_nif.c).  All four are dirty
+  NIF stubs for libsendslam_orb.so (send-slam_amd/nif/sendslam_nif.c).  All five are dirty
   CPU-bound NIFs; they return `{:error, {code, message}}` and never raise.
   """
   @on_load :load
@@ -9,6 +9,7 @@ defmodule SendSlam.HipNif do
   def set_calibration(_ref, _camera_id, _k8, _w, _h, _fps, _rgb), do: :erlang.nif_error(:nif_not_loaded)
   def extract(_ref, _camera_id, _pixels, _w, _h, _channels, _timestamp), do: :erlang.nif_error(:nif_not_loaded)
   def match(_ref, _query, _train, _th, _num, _den), do: :erlang.nif_error(:nif_not_loaded)
+  def track(_ref, _camera_id, _pixels, _w, _h, _channels, _timestamp), do: :erlang.nif_error(:nif_not_loaded)
 end
 
 defmodule SendSlam.HipBackend do
@@ -49,7 +50,6 @@ defmodule SendSlam.HipBackend do
        container_id: nil,
        last_seen: nil,
        calibrated: false,
-       prev_desc: nil,
        log: :queue.new()
      }}
   end
@@ -88,13 +88,24 @@ defmodule SendSlam.HipBackend do
       camera_id = Keyword.get(opts, :camera_id, 1)
       ts = Keyword.get(opts, :timestamp, System.monotonic_time(:nanosecond) / 1.0e9)
 
-      case SendSlam.HipNif.extract(ref, camera_id, Evision.Mat.to_binary(mat), w, h, c, ts) do
-        {:ok, n, _kps, desc} ->
-          matches = if s.prev_desc, do: SendSlam.HipNif.match(ref, desc, s.prev_desc, 50, 9, 10), else: nil
-          # pose estimation from `matches` is the next step (DESIGN.md); until the state is OK
-          # nothing is dispatched, exactly like the shim (orbslam3_mono_networked.cc:596)
-          _ = matches
-          {:noreply, %{s | prev_desc: desc, last_seen: now_ms()} |> log("frame #{camera_id}: #{n} keypoints")}
+      case SendSlam.HipNif.track(ref, camera_id, Evision.Mat.to_binary(mat), w, h, c, ts) do
+        {:ok, 2 = state, {px, py, pz}, {qx, qy, qz, qw}, {n, _m, inliers, _pts}} ->
+          # tracking state OK: the map SlamHandler forwards after unpacking a pose packet
+          # (slam_handler.ex:114-127; built by the shim at orbslam3_mono_networked.cc:225-282)
+          broadcast_pose(%{
+            "type" => "pose",
+            "timestamp" => ts,
+            "camera_id" => camera_id,
+            "tracking_state" => state,
+            "position" => %{"x" => px, "y" => py, "z" => pz},
+            "orientation" => %{"x" => qx, "y" => qy, "z" => qz, "w" => qw}
+          })
+
+          {:noreply, %{s | last_seen: now_ms()} |> log("frame #{camera_id}: #{n} keypoints, #{inliers} inliers")}
+
+        {:ok, state, _pos, _quat, {n, _m, _i, _p}} ->
+          # not OK: nothing is dispatched, exactly like the shim (orbslam3_mono_networked.cc:596)
+          {:noreply, %{s | last_seen: now_ms()} |> log("frame #{camera_id}: #{n} keypoints, state #{state}")}
 
         {:error, reason} ->
           # bad frame => log + skip, never crash (orbslam3_mono_networked.cc:523-551)
@@ -108,7 +119,7 @@ defmodule SendSlam.HipBackend do
   def handle_info({:broadcast_message, {:calibration, _calib}}, s), do: {:noreply, %{s | calibrated: false}}
   def handle_info(_other, s), do: {:noreply, s}
 
-  # what would be dispatched once poses exist: the string-keyed map of slam_handler.ex:127
+  # the string-keyed map of slam_handler.ex:127, to every process registered on PoseRegistry
   def broadcast_pose(pose_map) do
     Registry.dispatch(@pose_registry, :clients, fn entries ->
       for {pid, _} <- entries, do: send(pid, {:broadcast_pose, pose_map})

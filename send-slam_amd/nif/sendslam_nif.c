@@ -124,6 +124,32 @@ static ERL_NIF_TERM nif_match(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[
     return enif_make_tuple2(env, enif_make_atom(env, "ok"), ib);
 }
 
+/* track(ref, camera_id, pixels :: binary, width, height, channels, timestamp)
+ *   -> {:ok, tracking_state, {px, py, pz}, {qx, qy, qz, qw}, {n_keypoints, n_matches, n_inliers, n_map_points}} | error */
+static ERL_NIF_TERM nif_track(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    ctx_res *r;
+    ErlNifBinary pix;
+    int cam_id, w, h, ch;
+    double ts;
+    (void)argc;
+    if (!enif_get_resource(env, argv[0], CTX_TYPE, (void **)&r) || !enif_get_int(env, argv[1], &cam_id) ||
+        !enif_inspect_binary(env, argv[2], &pix) || !enif_get_int(env, argv[3], &w) || !enif_get_int(env, argv[4], &h) ||
+        !enif_get_int(env, argv[5], &ch) || !enif_get_double(env, argv[6], &ts))
+        return enif_make_badarg(env);
+    if (w <= 0 || h <= 0 || ch <= 0 || pix.size < (size_t)w * h * ch) return mk_error(env, SS_ERR_BAD_FRAME, "binary smaller than the frame");
+    ss_pose po;
+    int rc = ss_track(r->ctx, cam_id, pix.data, w, h, ch, w * ch, ts, &po);
+    if (rc != SS_OK) return mk_error(env, rc, ss_last_error(r->ctx));
+    ERL_NIF_TERM pos = enif_make_tuple3(env, enif_make_double(env, po.position[0]), enif_make_double(env, po.position[1]),
+                                        enif_make_double(env, po.position[2]));
+    ERL_NIF_TERM quat = enif_make_tuple4(env, enif_make_double(env, po.quaternion[0]), enif_make_double(env, po.quaternion[1]),
+                                         enif_make_double(env, po.quaternion[2]), enif_make_double(env, po.quaternion[3]));
+    ERL_NIF_TERM cnt = enif_make_tuple4(env, enif_make_int(env, po.n_keypoints), enif_make_int(env, po.n_matches),
+                                        enif_make_int(env, po.n_inliers), enif_make_int(env, po.n_map_points));
+    return enif_make_tuple5(env, enif_make_atom(env, "ok"), enif_make_int(env, po.tracking_state), pos, quat, cnt);
+}
+
 static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info)
 {
     (void)priv; (void)info;
@@ -136,6 +162,7 @@ static ErlNifFunc funcs[] = {
     {"set_calibration", 7, nif_set_calibration, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"extract", 7, nif_extract, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"match", 6, nif_match, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"track", 7, nif_track, ERL_NIF_DIRTY_JOB_CPU_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.SendSlam.HipNif, funcs, on_load, NULL, NULL, NULL)

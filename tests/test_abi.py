@@ -75,3 +75,18 @@ def test_product_constants_equal_oracle_constants():
         assert macro(prod, "SS_" + a) == macro(orc, "ORC_" + b), a
     taps = [int(macro(prod, f"SS_GAUSS_K{i}")) for i in range(4)]
     assert taps + taps[2::-1] == [int(v) for v in re.findall(r"\d+", macro(orc, "ORC_GAUSS_TAPS"))]
+
+
+def test_nif_glue_type_checks_against_the_c_abi():
+    """send-slam_amd/nif/sendslam_nif.c cannot be built here (no OTP); it is at least type-checked against
+    include/sendslam_orb.h with a declarations-only erl_nif.h, and must bind the entry points INTEGRATION.md lists."""
+    nif = os.path.join(ROOT, "send-slam_amd/nif/sendslam_nif.c")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                           "-I" + os.path.join(ROOT, "tests/native/erl_nif_decls"), "-I" + os.path.join(ROOT, "include"), nif])
+    text = open(nif).read()
+    for call in ["ss_create(", "ss_destroy(", "ss_set_calibration(", "ss_extract(", "ss_match(", "ss_track("]:
+        assert call in text, call
+    ex = open(os.path.join(ROOT, "send-slam_amd/nif/hip_backend.ex")).read()
+    for name, arity in re.findall(r'\{"(\w+)", (\d+), nif_\w+, ERL_NIF_DIRTY_JOB_CPU_BOUND\}', text):
+        m = re.search(r"def " + name + r"\(([^)]*)\), do: :erlang.nif_error", ex)
+        assert m and len(m.group(1).split(",")) == int(arity), f"{name}/{arity} has no matching Elixir stub"
