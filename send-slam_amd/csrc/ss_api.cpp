@@ -57,11 +57,13 @@ struct ss_ctx {
     ss_rtab *d_rtab = nullptr;
     uint32_t *d_tiles = nullptr, *d_tiles2 = nullptr;
 
-    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr, *flags = nullptr;
+    uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr;
     uint32_t *cell_cnt = nullptr;
     uint16_t *d_cinfo = nullptr;
     uint32_t *cand = nullptr, *qbuf0 = nullptr, *qbuf1 = nullptr;
-    uint16_t *corner_list = nullptr, *corner_cnt = nullptr; /* per tile: FAST corners (score > 0) */
+    uint32_t *bucket = nullptr; /* per cell: NMS survivors, unordered */
+    uint32_t *tsurv = nullptr, *thdr = nullptr; /* per 64x32 tile: survivor sub-lists and their count words */
+    uint32_t *d_tilecell = nullptr, *d_cell_units = nullptr;
     ss_qnode *nodes = nullptr;
     int32_t *lists = nullptr;
     uint32_t *sel = nullptr;
@@ -181,14 +183,16 @@ void free_geometry_buffers(ss_ctx *c)
     dev_free(c->pyr);
     dev_free(c->blur);
     dev_free(c->score);
-    dev_free(c->flags);
     dev_free(c->d_cinfo);
     dev_free(c->cell_cnt);
     dev_free(c->cand);
     dev_free(c->qbuf0);
     dev_free(c->qbuf1);
-    dev_free(c->corner_list);
-    dev_free(c->corner_cnt);
+    dev_free(c->bucket);
+    dev_free(c->tsurv);
+    dev_free(c->thdr);
+    dev_free(c->d_tilecell);
+    dev_free(c->d_cell_units);
     dev_free(c->nodes);
     dev_free(c->lists);
     dev_free(c->sel);
@@ -228,15 +232,19 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->score, B * g.block_bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->flags, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->d_cinfo, c->tabs.cinfo.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(c->d_cinfo, c->tabs.cinfo.data(), c->tabs.cinfo.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->cell_cnt, B * g.n_cells * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->cand, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf0, B * g.cand_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->qbuf1, B * g.cand_total * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->corner_list, B * g.tiles2_total * (size_t)(SS_TILE_W * SS_TILE_H2) * sizeof(uint16_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->corner_cnt, B * g.tiles2_total * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->bucket, B * g.bucket_total * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->tsurv, B * g.tiles2_total * (size_t)SS_TS_CAP * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->thdr, B * g.tiles2_total * (size_t)SS_TS_HDR * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tilecell, c->tabs.tilecell.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_tilecell, c->tabs.tilecell.data(), c->tabs.tilecell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->d_cell_units, c->tabs.cell_units.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_cell_units, c->tabs.cell_units.data(), c->tabs.cell_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->nodes, B * g.node_total * sizeof(ss_qnode)));
     HIP_TRY(c, hipMalloc((void **)&c->lists, B * g.item_total * 2 * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->sel, B * g.sel_total * sizeof(uint32_t)));
@@ -282,19 +290,18 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
     }
     {
-        /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map is this
-         * design's own intermediate) */
-        stage_timer t(c, "fast_blur", n * 2 * all_px);
-        ssk_fast_blur(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, n);
-    }
-    HIP_TRY(c, hipMemsetAsync(c->cell_cnt, 0, (size_t)n * g.n_cells * sizeof(uint32_t), s));
-    {
-        stage_timer t(c, "nms", 0);
-        ssk_nms(s, c->score, c->flags, c->dg, g, c->d_tiles2, c->corner_list, c->corner_cnt, c->d_cinfo, c->cell_cnt, n);
+        /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map and the
+         * survivor lists are this design's own intermediates) */
+        stage_timer t(c, "fast_blur_nms", n * 2 * all_px);
+        ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->d_tilecell, c->tsurv, c->thdr, c->state, n);
     }
     {
-        stage_timer t(c, "cells_emit", n * all_px);
-        ssk_cells_emit(s, c->score, c->flags, c->dg, g, c->cell_cnt, c->cand, c->state, n);
+        stage_timer t(c, "bucket_gather", 0);
+        ssk_bucket_gather(s, c->dg, g, c->d_cell_units, c->tsurv, c->thdr, c->bucket, c->cell_cnt, c->state, n);
+    }
+    {
+        stage_timer t(c, "cells_emit", 0);
+        ssk_cells_emit(s, c->bucket, c->dg, g, c->cell_cnt, c->cand, c->state, n);
     }
     {
         stage_timer t(c, "quadtree", 0);

@@ -11,6 +11,7 @@
  */
 #include "ss_geometry.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -128,7 +129,10 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     tabs->tiles.clear();
     tabs->tiles2.clear();
     tabs->cinfo.clear();
+    tabs->tilecell.clear();
+    tabs->cell_units.clear();
     uint32_t off = 0;
+    int bucket_base = 0, chunk_base = 0;
     int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile_base = 0, tile2_base = 0;
     for (int l = 0; l < p.n_levels; l++) {
         ss_level &L = g->lv[l];
@@ -193,6 +197,12 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
         L.cand_base = cand_base;
         L.cand_cap = align_up(((bw + L.n_cols) * (bh + L.n_rows)) / 4 + L.n_cols * L.n_rows + 64, 64);
         cand_base += L.cand_cap;
+        /* a cell evaluates at most w_cell x h_cell pixels and its survivors are never 8-adjacent */
+        L.bucket_cap = ((L.w_cell + 1) / 2) * ((L.h_cell + 1) / 2);
+        L.bucket_base = bucket_base;
+        bucket_base += L.bucket_cap * L.n_cols * L.n_rows;
+        L.chunk_base = chunk_base;
+        chunk_base += (L.n_cols * L.n_rows + 63) / 64;
         const int most = (L.quota + 3 > 4 * L.n_ini ? L.quota + 3 : 4 * L.n_ini);
         L.sel_base = sel_base;
         L.sel_cap = align_up(most + 5, 8);
@@ -219,6 +229,54 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
             for (int tx = 0; tx < L.tiles_x; tx++)
                 tabs->tiles2.push_back(((uint32_t)l << 20) | ((uint32_t)ty << 8) | (uint32_t)tx);
 
+        /* which cell windows a 64x32 tile meets, and over which (tile, sub-list) pairs a cell is spread */
+        {
+            const uint16_t *xin = tabs->cinfo.data() + L.xinfo_off, *yin = tabs->cinfo.data() + L.yinfo_off;
+            auto first_cell = [](const uint16_t *info, int from, int to) {
+                for (int p = from; p < to; p++)
+                    if (info[p] & SS_CI_VALID) return (int)(info[p] & SS_CI_CELL);
+                return 0;
+            };
+            for (int ty = 0; ty < L.tiles2_y; ty++)
+                for (int tx = 0; tx < L.tiles_x; tx++) {
+                    const int col0 = first_cell(xin, tx * SS_TILE_W, std::min((tx + 1) * SS_TILE_W, L.w));
+                    const int row0 = first_cell(yin, ty * SS_TILE_H2, std::min((ty + 1) * SS_TILE_H2, L.h));
+                    tabs->tilecell.push_back((uint32_t)col0 | ((uint32_t)row0 << 16));
+                }
+            const size_t ubase = tabs->cell_units.size();
+            tabs->cell_units.resize(ubase + (size_t)L.n_cols * L.n_rows * SS_CELL_UNITS, 0xFFFFFFFFu);
+            std::vector<int> x_lo(L.n_cols, 1 << 30), x_hi(L.n_cols, -1), y_lo(L.n_rows, 1 << 30), y_hi(L.n_rows, -1);
+            for (int p = 0; p < L.w; p++)
+                if (xin[p] & SS_CI_VALID) {
+                    const int c = xin[p] & SS_CI_CELL;
+                    x_lo[c] = std::min(x_lo[c], p);
+                    x_hi[c] = std::max(x_hi[c], p);
+                }
+            for (int p = 0; p < L.h; p++)
+                if (yin[p] & SS_CI_VALID) {
+                    const int c = yin[p] & SS_CI_CELL;
+                    y_lo[c] = std::min(y_lo[c], p);
+                    y_hi[c] = std::max(y_hi[c], p);
+                }
+            for (int ci = 0; ci < L.n_rows; ci++)
+                for (int cj = 0; cj < L.n_cols; cj++) {
+                    if (x_hi[cj] < 0 || y_hi[ci] < 0) continue; /* a cell the grid loop skips */
+                    int n_units = 0;
+                    for (int ty = y_lo[ci] / SS_TILE_H2; ty <= y_hi[ci] / SS_TILE_H2; ty++)
+                        for (int tx = x_lo[cj] / SS_TILE_W; tx <= x_hi[cj] / SS_TILE_W; tx++) {
+                            const int tile = L.tile2_base + ty * L.tiles_x + tx;
+                            const uint32_t tc = tabs->tilecell[tile];
+                            const int kc = cj - (int)(tc & 0xFFFFu), kr = ci - (int)(tc >> 16);
+                            if (kc < 0 || kc >= 3 || kr < 0 || kr >= 2 || n_units >= SS_CELL_UNITS) {
+                                *err = "unsupported cell / tile geometry at level " + std::to_string(l);
+                                return SS_ERR_INVALID_ARG;
+                            }
+                            tabs->cell_units[ubase + ((size_t)ci * L.n_cols + cj) * SS_CELL_UNITS + n_units++] =
+                                (uint32_t)tile | ((uint32_t)(kr * 3 + kc) << 24);
+                        }
+                }
+        }
+
         if (l > 0) {
             const ss_level &P = g->lv[l - 1];
             L.xtab_off = (int)tabs->rtab.size();
@@ -230,6 +288,8 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     g->block_bytes = off;
     g->n_cells = cell_base;
     g->cand_total = cand_base;
+    g->bucket_total = bucket_base;
+    g->chunks_total = chunk_base;
     g->sel_total = sel_base;
     g->node_total = node_base;
     g->item_total = item_base;

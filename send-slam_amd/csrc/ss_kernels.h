@@ -12,14 +12,17 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
                 int level, int n_frames);
-/* K2 + K6a fused: FAST response map, per-tile corner lists and the blurred pyramid from one staged tile */
-void ssk_fast_blur(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-                   const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames);
-void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
-             const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
-             uint32_t *cell_cnt, int n_frames);
-void ssk_cells_emit(hipStream_t s, const uint8_t *score, const uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames);
+/* K2 + K3a + K6a fused: FAST response map, in-window NMS into per-tile survivor sub-lists, blurred pyramid -- one
+ * staged tile, no global atomics */
+void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+                       const uint32_t *tiles, const uint16_t *cinfo, const uint32_t *tilecell, uint32_t *tsurv, uint32_t *thdr,
+                       ss_level_state *state, int n_frames);
+/* tile sub-lists -> per-cell buckets + count words (one thread per cell) */
+void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
+                       const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames);
+/* K3b: ranks the bucket entries of every cell into upstream's candidate order */
+void ssk_cells_emit(hipStream_t s, const uint32_t *bucket, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_cnt,
+                    uint32_t *cand, ss_level_state *state, int n_frames);
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
                   uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state,
                   int n_frames);

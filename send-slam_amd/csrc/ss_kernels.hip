@@ -180,23 +180,29 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* K2: FAST-9-16 response.  R = max over the 16 arcs of 9 contiguous ring pixels of        */
-/* min(v - p) and of min(p - v); a pixel is a corner at threshold t iff R > t and its      */
-/* cv::cornerScore is R - 1 for every such t, so ONE map serves iniTh and minTh.  Stored:  */
-/* R - 1 if R > minTh else 0.  64x32 tile per 256-thread block; the tile plus its 3-px    */
-/* ring halo is staged in LDS as aligned dwords.  The 7x7 Gaussian (K6a) needs exactly the same  */
-/* tile and halo, so it rides in the same kernel: one global read feeds both.                        */
+/* K2 + K3a + K6a: FAST-9-16 response, non-maximum suppression, Gaussian blur.            */
+/* R = max over the 16 arcs of 9 contiguous ring pixels of min(v - p) and of min(p - v); a  */
+/* pixel is a corner at threshold t iff R > t and its cv::cornerScore is R - 1 for every    */
+/* such t, so ONE map serves iniTh and minTh.  Stored: R - 1 if R > minTh else 0.           */
+/* 64x32 tile per 256-thread block.  The tile, a 1-px ring of neighbours (whose scores the  */
+/* NMS needs) and their 3-px FAST rings are staged in LDS as aligned dwords; the 7x7        */
+/* Gaussian (K6a) needs the same bytes, so it rides in the same kernel: one global read     */
+/* feeds all three.                                                                         */
+/* NMS (K3a) runs inside the FAST cell windows: cv::FAST is called per cell sub-image, so a */
+/* pixel competes only with neighbours of ITS window (FAST_t's ring buffers hold 0 outside  */
+/* it); the per-column / per-row tables say whether a pixel is evaluated at all and whether  */
+/* it is the first / last of its window.  A survivor at minTh that scores >= iniTh is also   */
+/* a survivor at iniTh and vice versa (every neighbour below iniTh is below it), so one      */
+/* unordered bucket per cell serves both thresholds: the cell's count word holds the number */
+/* of survivors (low half, = bucket slot allocator) and of those >= iniTh (high half).      */
 /* ------------------------------------------------------------------------------------ */
-#define FT_ROWS (SS_TILE_H2 + 6)
-#define FT_WORDS (SS_TILE_W / 4 + 2)
+#define FT_ROWS (SS_TILE_H2 + 8)        /* staged rows: y0 - 4 .. y0 + 35 */
+#define FT_BLUR_ROWS (SS_TILE_H2 + 6)   /* of which the blur uses y0 - 3 .. y0 + 34 */
+#define FT_WORDS (SS_TILE_W / 4 + 2)    /* staged bytes: x0 - 4 .. x0 + 67 */
+#define FT_HALO_PIXELS (2 * (SS_TILE_W + 2) + 2 * SS_TILE_H2)
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i16x2 as_i16x2(uint32_t v) { return __builtin_bit_cast(i16x2, v); }
-
-__device__ __forceinline__ int tile_byte(const uint32_t (&w)[3], int k) /* k compile-time */
-{
-    return (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-}
 
 __device__ __forceinline__ int reflect101(int p, int n)
 {
@@ -212,34 +218,47 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
-
 __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr,
                                                     uint8_t *__restrict__ score,
                                                     const ss_geom *__restrict__ g,
                                                     const uint32_t *__restrict__ tiles,
-                                                    uint16_t *__restrict__ corner_list,
-                                                    uint16_t *__restrict__ corner_cnt,
+                                                    const uint16_t *__restrict__ cinfo,
+                                                    const uint32_t *__restrict__ tilecell,
+                                                    uint32_t *__restrict__ tsurv,
+                                                    uint32_t *__restrict__ thdr,
+                                                    ss_level_state *__restrict__ state,
                                                     uint8_t *__restrict__ blur)
 {
     /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
      * so the vertical pass is four v_dot2_u32_u16 per output */
-    __shared__ uint32_t hpair[FT_ROWS / 2][SS_TILE_W];
+    __shared__ uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
-    __shared__ uint32_t out_tile[SS_TILE_H2][SS_TILE_W / 4];
-    __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2];
+    /* scores of the tile and of its 1-px ring: row ly + 1, byte lx + 4 (tile pixels dword-aligned) */
+    __shared__ uint32_t out_tile[SS_TILE_H2 + 2][FT_WORDS];
+    __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2 + FT_HALO_PIXELS + 4];
     __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H2];
+    __shared__ uint16_t xinf[SS_TILE_W], yinf[SS_TILE_H2];
+    __shared__ uint32_t s_kcnt[SS_TS_HDR]; /* count words of the tile's sub-lists */
     __shared__ int n_list, n_corner;
     const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const uint32_t t = tiles[tile];
     const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
     const ss_level &L = g->lv[level];
-    const size_t fb = (size_t)blockIdx.y * g->block_bytes + L.off;
+    const int frame = blockIdx.y;
+    const size_t fb = (size_t)frame * g->block_bytes + L.off;
     const uint8_t *img = pyr + fb;
     const int w = L.w, h = L.h, pitch = L.pitch;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
-    /* stage rows y0-3 .. y0+34, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
+    if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += 256) (&out_tile[0][0])[i] = 0;
+    if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = x0 + (int)threadIdx.x < w ? cinfo[L.xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
+    else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) {
+        const int k = (int)threadIdx.x - SS_TILE_W;
+        yinf[k] = y0 + k < h ? cinfo[L.yinfo_off + y0 + k] : (uint16_t)0;
+    }
+    /* stage rows y0-4 .. y0+35, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
      * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
      * the image are filled by BORDER_REFLECT_101 (what the blur needs; FAST never evaluates a
      * pixel whose ring leaves the image, so it does not care).  Rows are always reflected (4
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     for (int rr = 0; rr < 3; rr++) {
         const int r = ty + 16 * rr;
         if (r < FT_ROWS) {
-            const uint8_t *row = img + (size_t)reflect101(y0 - 3 + r, h) * pitch;
+            const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * pitch;
             if (inner_x) {
                 lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
                 if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
@@ -272,15 +291,15 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
      * d < -t.  Only a few % of the pixels pass; they are queued in LDS and scored in phase 2,
      * the rest get 0 without the 100-op arc search. */
     const int min_th = g->min_th;
+    const uint8_t *tile8 = (const uint8_t *)&lds[0][0];
     uint32_t cand_bits = 0; /* bit 4*rr + i: pixel i of row 2ty+rr passed */
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
         /* two pixels per operation: ring values go to the 16-bit halves of a dword (v_perm_b32),
          * differences and the min/max tree are v_pk_*_i16 */
-        const uint32_t u1 = lds[ly][tx + 1], n1 = lds[ly + 6][tx + 1];
-        const uint32_t m0 = lds[ly + 3][tx], m1 = lds[ly + 3][tx + 1], m2 = lds[ly + 3][tx + 2];
-        out_tile[ly][tx] = 0;
+        const uint32_t u1 = lds[ly + 1][tx + 1], n1 = lds[ly + 7][tx + 1];
+        const uint32_t m0 = lds[ly + 4][tx], m1 = lds[ly + 4][tx + 1], m2 = lds[ly + 4][tx + 2];
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) { /* pixels 2pr, 2pr+1 of the thread's four */
             constexpr uint32_t Z = 0x0C000C00u; /* selector bytes 1 and 3 = constant 0 */
@@ -304,7 +323,24 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         cand_bits &= cand_bits - 1;
         const int ly = 2 * ty + (bit >> 2), lx = 4 * tx + (bit & 3);
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)((ly << 8) | lx);
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
+    }
+    /* the same test for the 1-px ring around the tile (scores the NMS of the edge pixels needs) */
+    if (threadIdx.x < FT_HALO_PIXELS) {
+        const int i = threadIdx.x;
+        int lx, ly;
+        if (i < SS_TILE_W + 2) { lx = i - 1; ly = -1; }
+        else if (i < 2 * (SS_TILE_W + 2)) { lx = i - (SS_TILE_W + 2) - 1; ly = SS_TILE_H2; }
+        else if (i < 2 * (SS_TILE_W + 2) + SS_TILE_H2) { lx = -1; ly = i - 2 * (SS_TILE_W + 2); }
+        else { lx = SS_TILE_W; ly = i - 2 * (SS_TILE_W + 2) - SS_TILE_H2; }
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+            const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
+            const int v = c[0];
+            const int d0 = v - c[3 * (FT_WORDS * 4)], d8 = v - c[-3 * (FT_WORDS * 4)], d4 = v - c[3], d12 = v - c[-3];
+            const int dark = imin(imax(d0, d8), imax(d4, d12)), bright = imax(imin(d0, d8), imin(d4, d12));
+            if (imax(dark, -bright) > min_th) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
+        }
     }
     /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
      * window [x-3, x+4] */
@@ -312,9 +348,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
         constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
         uint16_t *h16 = (uint16_t *)&hpair[0][0];
-        for (int idx = threadIdx.x; idx < FT_ROWS * 16; idx += 256) {
-            const int r = idx >> 4, q = idx & 15;
-            const uint32_t w0 = lds[r][q], w1 = lds[r][q + 1], w2 = lds[r][q + 2];
+        for (int idx = threadIdx.x; idx < FT_BLUR_ROWS * 16; idx += 256) {
+            const int r = idx >> 4, q = idx & 15; /* blur row r = staged row r + 1 */
+            const uint32_t w0 = lds[r + 1][q], w1 = lds[r + 1][q + 1], w2 = lds[r + 1][q + 2];
             uint32_t hv[4];
             hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
             hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
@@ -330,12 +366,11 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     /* Phase 2, queued pixels only: R = max over the 16 arcs of min9(v - p) and of min9(p - v) */
     constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    const uint8_t *tile8 = (const uint8_t *)&lds[0][0];
     uint8_t *out8 = (uint8_t *)&out_tile[0][0];
     const int n = n_list;
     for (int e = threadIdx.x; e < n; e += 256) {
-        const int ly = list[e] >> 8, lx = list[e] & 0xFF;
-        const uint8_t *c = tile8 + (ly + 3) * (FT_WORDS * 4) + 4 + lx;
+        const int ly = (int)(list[e] >> 8) - 1, lx = (int)(list[e] & 0xFF) - 1;
+        const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
         const int v = c[0];
         int d[16];
 #pragma unroll
@@ -356,10 +391,46 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         }
         const int R = imax(dark, -bright);
         if (R > min_th) {
-            out8[ly * SS_TILE_W + lx] = (uint8_t)(R - 1);
-            corners[atomicAdd(&n_corner, 1)] = list[e];
+            out8[(ly + 1) * (FT_WORDS * 4) + 4 + lx] = (uint8_t)(R - 1);
+            if ((unsigned)lx < SS_TILE_W && (unsigned)ly < SS_TILE_H2) corners[atomicAdd(&n_corner, 1)] = (uint16_t)((ly << 8) | lx);
         }
     }
+    __syncthreads();
+    /* K3a on the tile's corners: 8 neighbours from LDS, window rules from the tables.  A survivor
+     * joins the sub-list of its cell window (a tile meets at most 3 x 2 of them); its slot comes
+     * from an LDS counter, so no global atomic is involved: pass 1 here allots the slots, pass 2
+     * (after the blur's vertical pass) knows the sub-list offsets and writes the records. */
+    const int nc = n_corner, ini_th = g->ini_th;
+    const uint32_t tc = tilecell[tile];
+    const int col0 = (int)(tc & 0xFFFFu), row0 = (int)(tc >> 16);
+    for (int e = threadIdx.x; e < nc; e += 256) {
+        const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
+        const uint32_t xi = xinf[lx], yi = yinf[ly];
+        uint16_t code = 0xFFFFu;
+        if ((xi & SS_CI_VALID) && (yi & SS_CI_VALID)) {
+            const uint8_t *c = out8 + (ly + 1) * (FT_WORDS * 4) + 4 + lx;
+            const int sc = c[0];
+            const bool left_ok = !(xi & SS_CI_LOW), right_ok = !(xi & SS_CI_HIGH);
+            const bool up_ok = !(yi & SS_CI_LOW), down_ok = !(yi & SS_CI_HIGH);
+            int m = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const bool ok = (dx < 0 ? left_ok : dx > 0 ? right_ok : true) &&
+                                    (dy < 0 ? up_ok : dy > 0 ? down_ok : true);
+                    m = imax(m, ok ? (int)c[dy * (FT_WORDS * 4) + dx] : 0);
+                }
+            if (sc > m) {
+                const int k = ((int)(yi & SS_CI_CELL) - row0) * 3 + ((int)(xi & SS_CI_CELL) - col0);
+                const uint32_t old = atomicAdd(&s_kcnt[k], 1u | (sc >= ini_th ? 0x10000u : 0u));
+                code = (uint16_t)((k << 12) | (old & 0xFFFu));
+            }
+        }
+        list[e] = code; /* the queue of phase 1 is free again */
+    }
+
     /* K6a vertical pass, two output rows per thread (rows 2ty and 2ty+1 read the same four row
      * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path */
     {
@@ -383,161 +454,149 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
         }
     }
-    __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
         const int ly = 2 * ty + rr, y = y0 + ly;
-        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ly][tx];
+        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ly + 1][tx + 1];
     }
-    /* corners (score > 0) go to this tile's slot of the corner list, any order: the sparse NMS
-     * pass works on these lists instead of sweeping the whole map.  A slot holds a full tile,
-     * so nothing can overflow and no global atomic is needed. */
-    const size_t slot = (size_t)blockIdx.y * g->tiles2_total + tile;
-    const int nc = n_corner;
-    uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
-    for (int e = threadIdx.x; e < nc; e += 256) cl[e] = corners[e];
-    if (threadIdx.x == 0) corner_cnt[slot] = (uint16_t)nc;
-}
-
-/* ------------------------------------------------------------------------------------ */
-/* K3a: non-maximum suppression inside the FAST cell windows, on the SPARSE corner list the  */
-/* FAST kernel left (a few % of the pixels).  cv::FAST runs per cell sub-image, so a pixel      */
-/* competes only with neighbours of ITS window (FAST_t's ring buffers hold 0 outside it); the  */
-/* per-column / per-row tables say whether a pixel is evaluated at all and whether it is the   */
-/* first / last of its window.  Output: a flag byte per corner pixel (bit 0 keep at iniTh,     */
-/* bit 1 keep at minTh; bytes where score == 0 are never written nor read) and, through sparse */
-/* atomics, the two survivor counts of every cell (low / high half of one word).               */
-/* ------------------------------------------------------------------------------------ */
-__global__ __launch_bounds__(64) void k_nms(const uint8_t *__restrict__ score, uint8_t *__restrict__ flags,
-                                            const ss_geom *__restrict__ g, const uint32_t *__restrict__ tiles,
-                                            const uint16_t *__restrict__ corner_list, const uint16_t *__restrict__ corner_cnt,
-                                            const uint16_t *__restrict__ cinfo, uint32_t *__restrict__ cell_cnt)
-{
-    const int frame = blockIdx.y;
-    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const size_t slot = (size_t)frame * g->tiles2_total + tile;
-    const int n = corner_cnt[slot];
-    if (n == 0) return;
-    const uint32_t t = tiles[tile];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
-    const ss_level &L = g->lv[level];
-    const size_t fb = (size_t)frame * g->block_bytes + L.off;
-    const uint8_t *sm = score + fb;
-    const uint16_t *cl = corner_list + slot * (SS_TILE_W * SS_TILE_H2);
-    const int pitch = L.pitch, ini_th = g->ini_th;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        const uint32_t rec = cl[i];
-        const int x = x0 + (int)(rec & 0xFF), y = y0 + (int)(rec >> 8);
-        const uint32_t xi = cinfo[L.xinfo_off + x], yi = cinfo[L.yinfo_off + y];
-        uint8_t out = 0;
-        if ((xi & SS_CI_VALID) && (yi & SS_CI_VALID)) {
-            const uint8_t *c = sm + (size_t)y * pitch + x;
-            const int s = c[0];
-            const bool left_ok = !(xi & SS_CI_LOW), right_ok = !(xi & SS_CI_HIGH);
-            const bool up_ok = !(yi & SS_CI_LOW), down_ok = !(yi & SS_CI_HIGH);
-            int m = 0, m_ini = 0;
+    __syncthreads();
+    const size_t tslot = (size_t)frame * g->tiles2_total + tile;
+    if (threadIdx.x < SS_TS_HDR) thdr[tslot * SS_TS_HDR + threadIdx.x] = s_kcnt[threadIdx.x];
+    for (int e = threadIdx.x; e < nc; e += 256) {
+        const uint32_t code = list[e];
+        if (code == 0xFFFFu) continue;
+        const int k = (int)(code >> 12);
+        int idx = (int)(code & 0xFFFu);
 #pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const bool ok = (dx < 0 ? left_ok : dx > 0 ? right_ok : true) &&
-                                    (dy < 0 ? up_ok : dy > 0 ? down_ok : true);
-                    const int nb = ok ? (int)c[dy * pitch + dx] : 0;
-                    m = imax(m, nb);
-                    m_ini = imax(m_ini, nb >= ini_th ? nb : 0);
-                }
-            const bool k_min = s > m, k_ini = s >= ini_th && s > m_ini;
-            out = (uint8_t)((k_ini ? 1 : 0) | (k_min ? 2 : 0));
-            if (out) {
-                const int cell = L.cell_base + (int)(yi & SS_CI_CELL) * L.n_cols + (int)(xi & SS_CI_CELL);
-                atomicAdd(cell_cnt + (size_t)frame * g->n_cells + cell, (k_min ? 1u : 0u) | (k_ini ? 0x10000u : 0u));
-            }
-        }
-        flags[fb + (size_t)y * pitch + x] = out; /* defined exactly where score != 0 */
+        for (int j = 0; j < SS_TS_CELLS - 1; j++) idx += j < k ? (int)(s_kcnt[j] & 0xFFFFu) : 0;
+        const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
+        if (idx < SS_TS_CAP)
+            tsurv[tslot * SS_TS_CAP + idx] = SS_PACK(x0 + lx - SS_MIN_BORDER, y0 + ly - SS_MIN_BORDER, out8[(ly + 1) * (FT_WORDS * 4) + 4 + lx]);
+        else
+            atomicExch(&state[(size_t)frame * SS_MAX_LEVELS_ + level].error, -5);
     }
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* K3b: ordered compaction, one wave per cell.  A cell that kept anything at iniTh uses its */
-/* iniTh survivors, otherwise its minTh survivors (the FAST(...,minThFAST) retry).  Output    */
-/* order = upstream's push_back order: cells row-major, pixels row-major inside a cell.  The  */
-/* window is read as aligned dwords of the flag map, several rows per wave instruction.       */
+/* K3a': one thread per grid cell gathers the cell's survivors from the sub-lists of the     */
+/* tiles its window is spread over (table built by the host) into the cell's bucket, and       */
+/* writes the cell's count word.  Plain loads and stores: every word is written by exactly     */
+/* one thread, nothing needs clearing between batches.                                         */
 /* ------------------------------------------------------------------------------------ */
-__device__ __forceinline__ int cell_count_of(uint32_t c) { return (c >> 16) ? (int)(c >> 16) : (int)(c & 0xFFFFu); }
-
-__global__ __launch_bounds__(64) void k_cells_emit(const uint8_t *__restrict__ score, const uint8_t *__restrict__ flags,
-                                                   const ss_geom *__restrict__ g, const uint32_t *__restrict__ cell_cnt,
-                                                   uint32_t *__restrict__ cand, ss_level_state *__restrict__ state)
+__global__ __launch_bounds__(256) void k_bucket_gather(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cell_units,
+                                                      const uint32_t *__restrict__ tsurv, const uint32_t *__restrict__ thdr,
+                                                      uint32_t *__restrict__ bucket, uint32_t *__restrict__ cell_cnt,
+                                                      ss_level_state *__restrict__ state)
 {
-    const int frame = blockIdx.y, cell = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int cell = (int)(blockIdx.x * 256 + threadIdx.x), frame = blockIdx.y;
+    if (cell >= g->n_cells) return;
     int level = 0;
     for (int l = 1; l < g->n_levels; l++)
         if (cell >= g->lv[l].cell_base) level = l;
     const ss_level &L = g->lv[level];
-    const int loc = cell - L.cell_base;
-    const int ci = loc / L.n_cols, cj = loc - ci * L.n_cols;
-    const int lane = lane_id();
-    const uint32_t *cnt = cell_cnt + (size_t)frame * g->n_cells;
-    const bool last_cell = loc == L.n_cols * L.n_rows - 1;
-
-    const uint32_t mine = cnt[cell];
-    const int count = cell_count_of(mine);
-    const bool use_ini = (mine >> 16) != 0;
-    int before = 0;
-    for (int c = L.cell_base + lane; c < cell; c += WAVE) before += cell_count_of(cnt[c]);
-    before = wave_sum(before);
-    ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
-    if (before + count > L.cand_cap) {
-        if (lane == 0) atomicExch(&st->error, -5);
-        return;
-    }
-    if (last_cell && lane == 0) st->n_cand = before + count;
-    if (count == 0) return;
-
-    const int max_bx = L.w - SS_EDGE_THRESHOLD + 3, max_by = L.h - SS_EDGE_THRESHOLD + 3;
-    const int ini_y = SS_MIN_BORDER + ci * L.h_cell, ini_x = SS_MIN_BORDER + cj * L.w_cell;
-    const int ex0 = ini_x + 3, ex1 = imin(ini_x + L.w_cell + 6, max_bx) - 3;
-    const int ey0 = ini_y + 3, ey1 = imin(ini_y + L.h_cell + 6, max_by) - 3;
-    const int g0 = ex0 >> 2, n_groups = ((ex1 - 1) >> 2) - g0 + 1; /* aligned dwords covering [ex0, ex1) */
-    const int rows_per_it = WAVE / n_groups;
-    const int r = lane / n_groups, gi = lane - r * n_groups;
-    const size_t fb = (size_t)frame * g->block_bytes + L.off;
-    const uint32_t bit = use_ini ? 0x01010101u : 0x02020202u;
-    uint32_t *out = cand + (size_t)frame * g->cand_total + L.cand_base;
-    int pos = before;
-    for (int yb = ey0; yb < ey1; yb += rows_per_it) {
-        const int y = yb + r;
-        const int xw = 4 * (g0 + gi);
-        uint32_t keep = 0, sc = 0;
-        if (r < rows_per_it && y < ey1) {
-            sc = *(const uint32_t *)(score + fb + (size_t)y * L.pitch + xw);
-            /* bytes outside [ex0, ex1) belong to the neighbouring cells */
-#pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (xw + b < ex0 || xw + b >= ex1) sc &= ~(0xFFu << (8 * b));
-            if (sc) {
-                keep = *(const uint32_t *)(flags + fb + (size_t)y * L.pitch + xw) & bit;
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (!(sc & (0xFFu << (8 * b)))) keep &= ~(0xFFu << (8 * b)); /* flag bytes exist only under corners */
-            }
+    uint32_t *bk = bucket + (size_t)frame * g->bucket_total + L.bucket_base + (size_t)(cell - L.cell_base) * L.bucket_cap;
+    const uint32_t *units = cell_units + (size_t)cell * SS_CELL_UNITS;
+    int n = 0, n_ini = 0;
+    for (int u = 0; u < SS_CELL_UNITS; u++) {
+        const uint32_t d = units[u];
+        if (d == 0xFFFFFFFFu) break;
+        const size_t tslot = (size_t)frame * g->tiles2_total + (d & 0xFFFFFFu);
+        const int k = (int)(d >> 24);
+        const uint32_t *hdr = thdr + tslot * SS_TS_HDR;
+        int pre = 0;
+        for (int j = 0; j < k; j++) pre += (int)(hdr[j] & 0xFFFFu);
+        const uint32_t word = hdr[k];
+        const int cnt = (int)(word & 0xFFFFu);
+        n_ini += (int)(word >> 16);
+        const uint32_t *src = tsurv + tslot * SS_TS_CAP + pre;
+        for (int i = 0; i < cnt; i++) {
+            if (n < L.bucket_cap && pre + i < SS_TS_CAP) bk[n] = src[i];
+            n++;
         }
-        const int c = __popc(keep);
-        int incl = c; /* inclusive prefix over lanes = row-major order */
+    }
+    if (n > L.bucket_cap) {
+        atomicExch(&state[(size_t)frame * SS_MAX_LEVELS_ + level].error, -5);
+        n = L.bucket_cap;
+    }
+    cell_cnt[(size_t)frame * g->n_cells + cell] = (uint32_t)n | ((uint32_t)n_ini << 16);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K3b: ordered compaction.  A cell that kept anything at iniTh uses its survivors that     */
+/* score >= iniTh, otherwise all its (minTh) survivors -- the FAST(..., minThFAST) retry.     */
+/* Output order = upstream's push_back order: cells row-major, pixels row-major inside a     */
+/* cell.  One 256-thread block per 64 consecutive cells of a level: offsets by a scan of the */
+/* count words, then one thread per bucket entry computes its rank among the entries of its  */
+/* cell (key = y : x) and writes it to its final position.                                   */
+/* ------------------------------------------------------------------------------------ */
+#define CE_CELLS 64
+__device__ __forceinline__ int cell_count_of(uint32_t c) { return (c >> 16) ? (int)(c >> 16) : (int)(c & 0xFFFFu); }
+
+__global__ __launch_bounds__(256) void k_cells_emit(const uint32_t *__restrict__ bucket, const ss_geom *__restrict__ g,
+                                                   const uint32_t *__restrict__ cell_cnt, uint32_t *__restrict__ cand,
+                                                   ss_level_state *__restrict__ state)
+{
+    __shared__ int s_all[CE_CELLS + 1], s_out[CE_CELLS + 1];
+    __shared__ uint32_t s_cnt[CE_CELLS];
+    __shared__ int s_red[4];
+    const int frame = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    int level = 0;
+    for (int l = 1; l < g->n_levels; l++)
+        if (chunk >= g->lv[l].chunk_base) level = l;
+    const ss_level &L = g->lv[level];
+    const int n_level_cells = L.n_cols * L.n_rows;
+    const int first = (chunk - L.chunk_base) * CE_CELLS;
+    const int nc = imin(CE_CELLS, n_level_cells - first);
+    const uint32_t *cnt = cell_cnt + (size_t)frame * g->n_cells + L.cell_base;
+    ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
+
+    int part = 0;
+    for (int c = tid; c < first; c += 256) part += cell_count_of(cnt[c]);
+    part = wave_sum(part);
+    if (lane == 0) s_red[tid >> 6] = part;
+    if (tid < CE_CELLS) s_cnt[tid] = tid < nc ? cnt[first + tid] : 0u;
+    __syncthreads();
+    const int before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if (tid < WAVE) {
+        const uint32_t word = s_cnt[tid];
+        int ia = imin((int)(word & 0xFFFFu), L.bucket_cap), io = cell_count_of(word);
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
-            const int v = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += v;
+            const int va = __shfl_up(ia, o, WAVE), vo = __shfl_up(io, o, WAVE);
+            if (lane >= o) { ia += va; io += vo; }
         }
-        if (c) {
-            int p = pos + incl - c;
+        s_all[tid + 1] = ia;
+        s_out[tid + 1] = before + io;
+        if (tid == 0) { s_all[0] = 0; s_out[0] = before; }
+    }
+    __syncthreads();
+    const int total_items = s_all[nc], total_out = s_out[nc];
+    if (total_out > L.cand_cap) {
+        if (tid == 0) atomicExch(&st->error, -5);
+        return;
+    }
+    if (first + nc == n_level_cells && tid == 0) st->n_cand = total_out;
+    const int ini_th = g->ini_th;
+    const uint32_t *bk_level = bucket + (size_t)frame * g->bucket_total + L.bucket_base;
+    uint32_t *out = cand + (size_t)frame * g->cand_total + L.cand_base;
+    for (int t = tid; t < total_items; t += 256) {
+        int c = 0; /* the cell whose entry range [s_all[c], s_all[c+1]) holds t */
 #pragma unroll
-            for (int b = 0; b < 4; b++)
-                if (keep & (0xFFu << (8 * b)))
-                    out[p++] = SS_PACK(xw + b - SS_MIN_BORDER, y - SS_MIN_BORDER, (sc >> (8 * b)) & 0xFFu);
+        for (int step = CE_CELLS / 2; step >= 1; step >>= 1)
+            if (c + step < nc && s_all[c + step] <= t) c += step;
+        const uint32_t word = s_cnt[c];
+        const bool use_ini = (word >> 16) != 0;
+        const int n_all = s_all[c + 1] - s_all[c];
+        const uint32_t *bk = bk_level + (size_t)(first + c) * L.bucket_cap;
+        const uint32_t rec = bk[t - s_all[c]];
+        if (use_ini && (int)(rec >> 24) < ini_th) continue;
+        const uint32_t key = rec & 0xFFFFFFu; /* y in bits 12..23 above x: row-major order */
+        int rank = 0;
+        for (int j = 0; j < n_all; j++) {
+            const uint32_t o = bk[j];
+            rank += ((!use_ini || (int)(o >> 24) >= ini_th) && (o & 0xFFFFFFu) < key) ? 1 : 0;
         }
-        pos += __shfl(incl, WAVE - 1, WAVE);
+        out[s_out[c] + rank] = rec;
     }
 }
 
@@ -1538,27 +1597,24 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
     }
 }
 
-void ssk_fast_blur(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-                   const uint32_t *tiles, uint16_t *corner_list, uint16_t *corner_cnt, int n_frames)
+void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
+                       const uint32_t *tiles, const uint16_t *cinfo, const uint32_t *tilecell, uint32_t *tsurv, uint32_t *thdr,
+                       ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, corner_list, corner_cnt,
-                       blur);
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, cinfo, tilecell, tsurv,
+                       thdr, state, blur);
 }
-
-void ssk_nms(hipStream_t s, const uint8_t *score, uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
-             const uint32_t *tiles, const uint16_t *corner_list, const uint16_t *corner_cnt, const uint16_t *cinfo,
-             uint32_t *cell_cnt, int n_frames)
+void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
+                       const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_nms, dim3(hg.tiles2_total, n_frames), dim3(64), 0, s, score, flags, dg, tiles, corner_list, corner_cnt,
-                       cinfo, cell_cnt);
+    hipLaunchKernelGGL(k_bucket_gather, dim3((hg.n_cells + 255) / 256, n_frames), dim3(256), 0, s, dg, cell_units, tsurv, thdr, bucket,
+                       cell_cnt, state);
 }
-
-void ssk_cells_emit(hipStream_t s, const uint8_t *score, const uint8_t *flags, const ss_geom *dg, const ss_geom &hg,
-                    const uint32_t *cell_cnt, uint32_t *cand, ss_level_state *state, int n_frames)
+void ssk_cells_emit(hipStream_t s, const uint32_t *bucket, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_cnt,
+                    uint32_t *cand, ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_cells_emit, dim3(hg.n_cells, n_frames), dim3(64), 0, s, score, flags, dg, cell_cnt, cand, state);
+    hipLaunchKernelGGL(k_cells_emit, dim3(hg.chunks_total, n_frames), dim3(256), 0, s, bucket, dg, cell_cnt, cand, state);
 }
-
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
                   uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state, int n_frames)
 {

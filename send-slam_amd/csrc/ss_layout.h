@@ -8,7 +8,12 @@
  *                        row pitch lv[l].pitch (multiple of 64 B -> every row starts on a
  *                        64-B line, dword/dwordx4 row loads are aligned), no border stored
  *                        (DESIGN.md "no stored border").
- *   cell_cnt             one int per grid cell, all levels (cell_base + row*n_cols + col)
+ *   tsurv / thdr         NMS survivors as the FAST kernel leaves them: per 64x32 tile, up to
+ *                        SS_TS_CELLS sub-lists (one per cell window the tile meets) packed back to
+ *                        back, and their count words (survivors low half, those >= iniTh high half)
+ *   cell_cnt             one count word per grid cell, all levels (cell_base + row*n_cols + col)
+ *   bucket               the survivors of each cell, unordered (bucket_base + cell * bucket_cap),
+ *                        gathered from the tile sub-lists
  *   cand                 packed candidates, level l at cand_base, upstream order
  *   sel                  per-level quadtree survivors, level l at sel_base, list order
  *   qt_* scratch         quadtree ping-pong record buffers, node table, sort items
@@ -26,6 +31,12 @@
 #define SS_TILE_W 64
 #define SS_TILE_H 16
 #define SS_TILE_H2 32 /* tall tiles for the FAST and blur kernels */
+/* NMS survivors of one 64x32 tile: a tile meets at most 3 x 2 cell windows (cells are >= 35 px) and
+ * survivors of ONE window are never 8-adjacent, so <= (32 + 1) * (16 + 1) of them */
+#define SS_TS_CAP 576
+#define SS_TS_CELLS 6   /* sub-lists per tile: (cell row - first row) * 3 + (cell col - first col) */
+#define SS_TS_HDR 8     /* header words per tile (SS_TS_CELLS count words, padded) */
+#define SS_CELL_UNITS 12 /* (tile, sub-list) pairs one cell can be spread over */
 
 #define SS_PACK(x, y, r) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
 #define SS_PX(p) ((int)((p) & 0xFFFu))
@@ -40,6 +51,8 @@ typedef struct {
     int32_t cell_base;
     int32_t quota;
     int32_t cand_base, cand_cap;
+    int32_t bucket_base, bucket_cap; /* NMS survivors per cell: entries per cell, first entry of the level */
+    int32_t chunk_base;              /* K3b blocks: 64 cells each */
     int32_t sel_base, sel_cap;
     int32_t node_base, node_cap; /* quadtree nodes */
     int32_t item_base, item_cap; /* quadtree sort items / expandable lists */
@@ -67,6 +80,8 @@ typedef struct {
     uint32_t block_bytes;   /* one pyramid block */
     int32_t n_cells;        /* all levels */
     int32_t cand_total;     /* u32 per frame */
+    int32_t bucket_total;   /* u32 per frame */
+    int32_t chunks_total;
     int32_t sel_total;
     int32_t node_total;
     int32_t item_total;

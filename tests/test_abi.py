@@ -90,3 +90,15 @@ def test_nif_glue_type_checks_against_the_c_abi():
     for name, arity in re.findall(r'\{"(\w+)", (\d+), nif_\w+, ERL_NIF_DIRTY_JOB_CPU_BOUND\}', text):
         m = re.search(r"def " + name + r"\(([^)]*)\), do: :erlang.nif_error", ex)
         assert m and len(m.group(1).split(",")) == int(arity), f"{name}/{arity} has no matching Elixir stub"
+
+
+def test_geometry_tables_hold_what_the_kernels_assume(tmp_path):
+    """Sweep of ss_build_geometry over ~30k image sizes and three scale factors (host build of the product
+    source): a size either builds or is 'too small'; a 64x32 tile meets at most 3 x 2 cell windows; every
+    evaluated pixel maps to exactly one (tile, sub-list) unit of its cell (tests/native/geometry_sweep.cpp)."""
+    exe = str(tmp_path / "geometry_sweep")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests/native/geometry_sweep.cpp"),
+                           os.path.join(ROOT, "send-slam_amd/csrc/ss_geometry.cpp")])
+    out = subprocess.run([exe, "7"], capture_output=True, text=True)
+    assert out.returncode == 0 and "built=" in out.stdout, out.stdout[-2000:]
