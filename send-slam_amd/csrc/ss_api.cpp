@@ -231,7 +231,7 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMemcpy(c->d_tiles2, c->tabs.tiles2.data(), c->tabs.tiles2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
-    HIP_TRY(c, hipMalloc((void **)&c->score, B * g.block_bytes));
+    /* c->score (the FAST response map) is allocated by the first ss_debug_fetch(2): no kernel reads it */
     HIP_TRY(c, hipMalloc((void **)&c->d_cinfo, c->tabs.cinfo.size() * sizeof(uint16_t)));
     HIP_TRY(c, hipMemcpy(c->d_cinfo, c->tabs.cinfo.data(), c->tabs.cinfo.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->cell_cnt, B * g.n_cells * sizeof(uint32_t)));
@@ -750,6 +750,15 @@ int ss_debug_fetch(ss_ctx *c, int what, int frame, int level, void *dst, int64_t
     const ss_geom &g = c->hg;
     const ss_level &L = g.lv[level];
     if (what >= 0 && what <= 2) {
+        if (what == 2 && !c->score) {
+            /* the response map is not kept in normal operation: allocate it and run the FAST kernel
+             * again on the pyramid of the last batch (same kernel, same outputs, plus the map);
+             * from now on this context keeps it */
+            HIP_TRY(c, hipMalloc((void **)&c->score, (size_t)c->params.max_batch * g.block_bytes));
+            ssk_fast_blur_nms(c->stream, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->d_tilecell, c->tsurv,
+                              c->thdr, c->state, c->last_n_frames);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
         const uint8_t *base = what == 0 ? c->pyr : what == 1 ? c->blur : c->score;
         const int64_t need = (int64_t)L.w * L.h;
         if (dst_bytes < need) return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: dst too small");

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
                                                     ss_level_state *__restrict__ state,
                                                     uint8_t *__restrict__ blur)
 {
+    /* `score` may be NULL: no later kernel reads the response map (it exists for stage-by-stage tests) */
     /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
      * so the vertical pass is four v_dot2_u32_u16 per output */
     __shared__ uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
@@ -454,10 +455,12 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
             if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
         }
     }
+    if (score) {
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int ly = 2 * ty + rr, y = y0 + ly;
-        if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ly + 1][tx + 1];
+        for (int rr = 0; rr < 2; rr++) {
+            const int ly = 2 * ty + rr, y = y0 + ly;
+            if (y < h && x0 + 4 * tx < pitch) *(uint32_t *)(score + fb + (size_t)y * pitch + x0 + 4 * tx) = out_tile[ly + 1][tx + 1];
+        }
     }
     __syncthreads();
     const size_t tslot = (size_t)frame * g->tiles2_total + tile;
@@ -478,47 +481,59 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* K3a': one thread per grid cell gathers the cell's survivors from the sub-lists of the     */
-/* tiles its window is spread over (table built by the host) into the cell's bucket, and       */
-/* writes the cell's count word.  Plain loads and stores: every word is written by exactly     */
-/* one thread, nothing needs clearing between batches.                                         */
+/* K3a': 16 lanes per grid cell gather the cell's survivors from the sub-lists of the tiles   */
+/* its window is spread over (table built by the host) into the cell's bucket and write the   */
+/* cell's count word.  Plain loads and stores: every word is written by exactly one thread,    */
+/* nothing needs clearing between batches.                                                     */
 /* ------------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void k_bucket_gather(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cell_units,
                                                       const uint32_t *__restrict__ tsurv, const uint32_t *__restrict__ thdr,
                                                       uint32_t *__restrict__ bucket, uint32_t *__restrict__ cell_cnt,
                                                       ss_level_state *__restrict__ state)
 {
-    const int cell = (int)(blockIdx.x * 256 + threadIdx.x), frame = blockIdx.y;
-    if (cell >= g->n_cells) return;
+    /* 16 lanes per cell, one per (tile, sub-list) unit: the loads of all units are in flight together */
+    const int gid = (int)(blockIdx.x * 256 + threadIdx.x), frame = blockIdx.y;
+    const int cell = gid >> 4, u = gid & 15;
+    const bool live = cell < g->n_cells;
     int level = 0;
     for (int l = 1; l < g->n_levels; l++)
-        if (cell >= g->lv[l].cell_base) level = l;
+        if (live && cell >= g->lv[l].cell_base) level = l;
     const ss_level &L = g->lv[level];
-    uint32_t *bk = bucket + (size_t)frame * g->bucket_total + L.bucket_base + (size_t)(cell - L.cell_base) * L.bucket_cap;
-    const uint32_t *units = cell_units + (size_t)cell * SS_CELL_UNITS;
-    int n = 0, n_ini = 0;
-    for (int u = 0; u < SS_CELL_UNITS; u++) {
-        const uint32_t d = units[u];
-        if (d == 0xFFFFFFFFu) break;
+    const uint32_t d = live && u < SS_CELL_UNITS ? cell_units[(size_t)cell * SS_CELL_UNITS + u] : 0xFFFFFFFFu;
+    int cnt = 0, ini = 0;
+    const uint32_t *src = tsurv;
+    if (d != 0xFFFFFFFFu) {
         const size_t tslot = (size_t)frame * g->tiles2_total + (d & 0xFFFFFFu);
         const int k = (int)(d >> 24);
         const uint32_t *hdr = thdr + tslot * SS_TS_HDR;
         int pre = 0;
-        for (int j = 0; j < k; j++) pre += (int)(hdr[j] & 0xFFFFu);
-        const uint32_t word = hdr[k];
-        const int cnt = (int)(word & 0xFFFFu);
-        n_ini += (int)(word >> 16);
-        const uint32_t *src = tsurv + tslot * SS_TS_CAP + pre;
-        for (int i = 0; i < cnt; i++) {
-            if (n < L.bucket_cap && pre + i < SS_TS_CAP) bk[n] = src[i];
-            n++;
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < SS_TS_CELLS; j++) {
+            const uint32_t hw = hdr[j];
+            pre += j < k ? (int)(hw & 0xFFFFu) : 0;
+            word = j == k ? hw : word;
         }
+        cnt = imin((int)(word & 0xFFFFu), imax(SS_TS_CAP - pre, 0));
+        ini = (int)(word >> 16);
+        src = tsurv + tslot * SS_TS_CAP + pre;
     }
-    if (n > L.bucket_cap) {
-        atomicExch(&state[(size_t)frame * SS_MAX_LEVELS_ + level].error, -5);
-        n = L.bucket_cap;
+    int incl = cnt, ini_sum = ini;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int v = __shfl_up(incl, o, 16), w = __shfl_up(ini_sum, o, 16);
+        if (u >= o) { incl += v; ini_sum += w; }
     }
-    cell_cnt[(size_t)frame * g->n_cells + cell] = (uint32_t)n | ((uint32_t)n_ini << 16);
+    const int total = __shfl(incl, 15, 16), total_ini = __shfl(ini_sum, 15, 16);
+    if (!live) return;
+    uint32_t *bk = bucket + (size_t)frame * g->bucket_total + L.bucket_base + (size_t)(cell - L.cell_base) * L.bucket_cap;
+    const int pos = incl - cnt;
+    for (int i = 0; i < cnt; i++)
+        if (pos + i < L.bucket_cap) bk[pos + i] = src[i];
+    if (u == 0) {
+        if (total > L.bucket_cap) atomicExch(&state[(size_t)frame * SS_MAX_LEVELS_ + level].error, -5);
+        cell_cnt[(size_t)frame * g->n_cells + cell] = (uint32_t)imin(total, L.bucket_cap) | ((uint32_t)total_ini << 16);
+    }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1607,7 +1622,7 @@ void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
                        const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_bucket_gather, dim3((hg.n_cells + 255) / 256, n_frames), dim3(256), 0, s, dg, cell_units, tsurv, thdr, bucket,
+    hipLaunchKernelGGL(k_bucket_gather, dim3((hg.n_cells * 16 + 255) / 256, n_frames), dim3(256), 0, s, dg, cell_units, tsurv, thdr, bucket,
                        cell_cnt, state);
 }
 void ssk_cells_emit(hipStream_t s, const uint32_t *bucket, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_cnt,
