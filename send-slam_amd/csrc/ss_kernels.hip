@@ -91,6 +91,25 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t *__restrict__ src,
     *(uint32_t *)(pyr + (size_t)blockIdx.z * g->block_bytes + g->lv[0].off + (size_t)y * pitch + x4) = out;
 }
 
+/* 1-channel input whose rows are 16-byte aligned: 16 pixels per thread, dwordx4 in, dwordx4 out */
+__global__ __launch_bounds__(256) void k_ingest_gray16(const uint8_t *__restrict__ src, int64_t row_stride, int64_t frame_stride,
+                                                       uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g)
+{
+    const int w = g->lv[0].w, h = g->lv[0].h, pitch = g->lv[0].pitch;
+    const int x16 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 16;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h || x16 >= w) return;
+    const uint8_t *sp = src + (int64_t)blockIdx.z * frame_stride + (int64_t)y * row_stride + x16;
+    uint8_t *dp = pyr + (size_t)blockIdx.z * g->block_bytes + g->lv[0].off + (size_t)y * pitch + x16;
+    if (x16 + 16 <= w) {
+        *(uint4 *)dp = *(const uint4 *)sp;
+    } else { /* last, partial group of the row: the pitch covers it, the source row may not */
+        uint32_t out[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 16; i++) out[i >> 2] |= (uint32_t)sp[imin(i, w - 1 - x16)] << (8 * (i & 3));
+        *(uint4 *)dp = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* K1: one pyramid step.  Host tables hold OpenCV's fixed-point taps (ss_geometry.cpp).   */
 /* ------------------------------------------------------------------------------------ */
@@ -1593,6 +1612,11 @@ __global__ __launch_bounds__(256) void k_match_stream(const uint32_t *__restrict
 void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride, int64_t frame_stride,
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames)
 {
+    if (channels == 1 && ((uintptr_t)src % 16) == 0 && row_stride % 16 == 0 && frame_stride % 16 == 0) {
+        dim3 grid16((hg.lv[0].w + 1023) / 1024, (hg.lv[0].h + 3) / 4, n_frames);
+        hipLaunchKernelGGL(k_ingest_gray16, grid16, dim3(256), 0, s, (const uint8_t *)src, row_stride, frame_stride, pyr, dg);
+        return;
+    }
     dim3 grid((hg.lv[0].w + 255) / 256, (hg.lv[0].h + 3) / 4, n_frames);
     hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, (const uint8_t *)src, channels, row_stride, frame_stride,
                        c0, c1, c2, pyr, dg);

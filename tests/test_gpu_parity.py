@@ -235,6 +235,29 @@ def test_batch_device_path_matches_single_frame_path(oracle):
         prev = odesc
 
 
+@pytest.mark.parametrize("w,stride,offset", [(330, 336, 0), (336, 336, 0), (330, 352, 16), (330, 333, 0), (320, 320, 4)])
+def test_batch_device_strides_and_alignments(oracle, w, stride, offset):
+    """Device batches with padded rows and odd base addresses: the 16-byte ingest path (aligned base and
+    strides, including a last partial 16-px group) and the byte path give the oracle's result."""
+    import torch
+    h, nf, B = 250, 400, 3
+    frames = np.stack([synth.frame(60 + b, w, h) for b in range(B)])
+    buf = np.full((B * h * stride + 64,), 0xA5, np.uint8)
+    for b in range(B):
+        for y in range(h):
+            o = offset + (b * h + y) * stride
+            buf[o:o + w] = frames[b, y]
+    d = torch.from_numpy(buf).to("cuda:0")
+    assert d.data_ptr() % 256 == 0
+    with binding.OrbContext(0, n_features=nf, max_batch=4) as ctx:
+        ctx.extract_batch_device(d.data_ptr() + offset, B, w, h, 1, stride, h * stride)
+        got = [ctx.fetch_frame(b) for b in range(B)]
+    p = oracle.default_params(n_features=nf)
+    for b in range(B):
+        okps, odesc, _ = oracle.extract(frames[b], p)
+        assert got[b][0].tobytes() == okps.tobytes() and np.array_equal(got[b][1], odesc)
+
+
 def test_full_size_properties_metric_config():
     """BASELINE.json metric config (1280x720, 2000 kp): size-independent properties."""
     img = synth.frame(30, 1280, 720)
