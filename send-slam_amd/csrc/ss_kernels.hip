@@ -1267,8 +1267,10 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
                                                          const int32_t *__restrict__ n_kp,
                                                          ss_keypoint *__restrict__ kps, uint8_t *__restrict__ desc)
 {
-    const int frame = blockIdx.y;
-    const int slot = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    /* all blocks of a frame on one XCD: keypoints whose patches share 64-B lines then share an L2 */
+    const int logical = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+    const int frame = logical / (int)gridDim.x;
+    const int slot = rfl((logical - frame * (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6));
     if (slot >= n_kp[frame]) return;
     const int lane = lane_id();
     const uint32_t ref = kp_ref[(size_t)frame * g->kcap + slot];
@@ -1282,13 +1284,24 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     /* IC_Angle: the 31-row patch around the keypoint is staged in LDS as aligned dwords
      * (5 coalesced loads per lane instead of 16 byte gathers); lane = (row, half) of the disc */
     __shared__ uint32_t patch_all[4][31][10];
+    /* ... and so is the 37 x 37 window of the blurred level the steered pattern can reach (|offset| <= 18):
+     * both sets of loads are in flight together, and the 512 samples become LDS byte reads instead of
+     * global gathers that touch up to 37 lines per instruction */
+    __shared__ uint32_t bpatch_all[4][37][10];
     uint32_t(*patch)[10] = patch_all[threadIdx.x >> 6];
+    uint32_t(*bpatch)[10] = bpatch_all[threadIdx.x >> 6];
     const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
+    const int bx0 = (kx - 18) & ~3;
     {
         const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
         for (int idx = lane; idx < 31 * 10; idx += WAVE) {
             const int r = idx / 10, c = idx - r * 10;
             patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
+        }
+        const uint8_t *b0 = blur + fb + (size_t)(ky - 18) * pitch + bx0;
+        for (int idx = lane; idx < 37 * 10; idx += WAVE) {
+            const int r = idx / 10, c = idx - r * 10;
+            bpatch[r][c] = *(const uint32_t *)(b0 + (size_t)r * pitch + 4 * c);
         }
     }
     wave_sync();
@@ -1316,7 +1329,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     ss_sincosf_deg(angle, &b, &a);
 
     /* steered rBRIEF */
-    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx;
+    const uint8_t *center = (const uint8_t *)&bpatch[18][0] + (kx - bx0);
     uint64_t words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        const int t0 = center[r0 * 40 + c0], t1 = center[r1 * 40 + c1];
         words[k] = __ballot(t0 < t1);
     }
     if (lane == 0) {
