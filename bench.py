@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--contexts", type=int, default=3, help="camera batches in flight per GPU")
+    ap.add_argument("--contexts", type=int, default=4, help="camera batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="extract_match", choices=["extract_match", "loop_closure"],
                     help="extract_match = the BASELINE.json metric (default); loop_closure = config 5: one 2000-descriptor "

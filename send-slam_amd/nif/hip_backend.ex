@@ -39,8 +39,13 @@ defmodule SendSlam.HipBackend do
   def status(pid), do: GenServer.call(pid, :status, 5_000)
   def logs(pid, lines \\ 100), do: GenServer.call(pid, {:logs, lines}, 15_000)
 
+  # `auto_restart: true` (the option application.ex:94 passes and DockerHandler never reads): the
+  # backend brings itself up in init/1, so a supervisor restart relaunches it -- with DockerHandler the
+  # only :start_container call is the one in application.ex:117, made once at boot.
   @impl true
   def init(opts) do
+    if Keyword.get(opts, :auto_restart, false), do: send(self(), :auto_start)
+
     {:ok,
      %{
        device: Keyword.get(opts, :device, 0),
@@ -116,6 +121,14 @@ defmodule SendSlam.HipBackend do
     end
   end
 
+  def handle_info(:auto_start, %{container_id: nil} = s) do
+    case handle_call(:start_container, nil, s) do
+      {:reply, _reply, s2} -> {:noreply, s2}
+      {:stop, reason, _reply, s2} -> {:stop, reason, s2}
+    end
+  end
+
+  def handle_info(:auto_start, s), do: {:noreply, s}
   def handle_info({:broadcast_message, {:calibration, _calib}}, s), do: {:noreply, %{s | calibrated: false}}
   def handle_info(_other, s), do: {:noreply, s}
 

@@ -33,7 +33,7 @@ def os_prefixed_env(prefix: str = "ORBSLAM3_") -> Dict[str, str]:
 
 class HipBackend:
     def __init__(self, port: int = 5000, device: int = 0, name: str = "net-orbslam", env: Optional[dict] = None,
-                 binary: str = FRONTDOOR, log_lines: int = 2000):
+                 binary: str = FRONTDOOR, log_lines: int = 2000, auto_restart: bool = False):
         merged = dict(os_prefixed_env())
         merged.update({str(k): str(v) for k, v in (env or {}).items()})
         merged.setdefault("ORB_SLAM3_WS_PORT", str(port))
@@ -47,6 +47,11 @@ class HipBackend:
         self._proc: Optional[subprocess.Popen] = None
         self._log = collections.deque(maxlen=log_lines)
         self._reader: Optional[threading.Thread] = None
+        # auto_restart (application.ex:94 passes it, DockerHandler never reads it): poll() relaunches an
+        # exited backend instead of only reporting it -- the reference's restart path never relaunches
+        # (application.ex:117 is the single start_container call)
+        self.auto_restart = auto_restart
+        self.restarts = 0
 
     def start_container(self):
         if self.container_id is not None:
@@ -83,6 +88,10 @@ class HipBackend:
             self.last_seen = int(time.monotonic() * 1000)
             return ("ok", self.state)
         self.state = "exited"
+        if self.auto_restart:
+            self.container_id = None
+            self.restarts += 1
+            return self.start_container()
         return ("error", "container_not_running")
 
     def stop_container(self):
