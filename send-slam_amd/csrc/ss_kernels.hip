@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
                                                     const ss_rtab *__restrict__ rtab, int level)
 {
     __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
+    __shared__ uint32_t hbuf[RS_ROWS][SS_TILE_W / 2]; /* horizontal results, two u16 per word */
     __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
@@ -172,27 +173,37 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     }
     __syncthreads();
 
+    /* Horizontal pass once per SOURCE row (as cv::resize's row buffers do): at scale 1.2 a source row
+     * feeds 1.7 destination rows, so this saves a third of the multiplies.  hbuf holds (h >> 4), u16. */
+    const int n_src = gy1 - gy0 + 1; /* <= RS_ROWS */
+    {
+        const int q = threadIdx.x & 31; /* column pair 2q, 2q + 1 */
+        const ss_rtab ra = xt[2 * q], rb = xt[2 * q + 1];
+        for (int r = threadIdx.x >> 5; r < n_src; r += 8) {
+            const uint8_t *l = (const uint8_t *)&lds[r][0] - gx0;
+            const uint32_t ha = (uint32_t)(l[ra.s0] * ra.a0 + l[ra.s1] * ra.a1) >> 4;
+            const uint32_t hb = (uint32_t)(l[rb.s0] * rb.a0 + l[rb.s1] * rb.a1) >> 4;
+            hbuf[r][q] = ha | (hb << 16);
+        }
+    }
+    __syncthreads();
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int dx4 = x0 + 4 * tx;
     if (dx4 >= D.w) return;
-    ss_rtab rx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) rx[i] = xt[4 * tx + i];
 #pragma unroll
     for (int rr = 0; rr < RS_TILE_H / 16; rr++) {
         const int ly = ty + 16 * rr, dy = y0 + ly;
         if (dy >= D.h) break;
         const ss_rtab ry = yt[ly];
-        const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
-        const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
-        const int b0 = ry.a0, b1 = ry.a1;
+        const uint32_t *h0 = &hbuf[ry.s0 - gy0][2 * tx], *h1 = &hbuf[ry.s1 - gy0][2 * tx];
+        const uint32_t b0 = (uint32_t)ry.a0, b1 = (uint32_t)ry.a1;
         uint32_t out = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int h0 = l0[rx[i].s0] * rx[i].a0 + l0[rx[i].s1] * rx[i].a1;
-            const int h1 = l1[rx[i].s0] * rx[i].a0 + l1[rx[i].s1] * rx[i].a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-            out |= ((uint32_t)v & 0xFFu) << (8 * i);
+        for (int i = 0; i < 2; i++) {
+            const uint32_t p0 = h0[i], p1 = h1[i];
+            const uint32_t va = (((b0 * (p0 & 0xFFFFu)) >> 16) + ((b1 * (p1 & 0xFFFFu)) >> 16) + 2) >> 2;
+            const uint32_t vb = (((b0 * (p0 >> 16)) >> 16) + ((b1 * (p1 >> 16)) >> 16) + 2) >> 2;
+            out |= ((va & 0xFFu) | ((vb & 0xFFu) << 8)) << (16 * i);
         }
         *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
     }
@@ -284,21 +295,35 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
      * pixel whose ring leaves the image, so it does not care).  Rows are always reflected (4
      * ops); columns only in the tiles that touch the left / right image edge (block-uniform). */
     const bool inner_x = x0 >= 4 && x0 + 68 <= w;
+    if (inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h) {
+        /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
+        const uint8_t *tile0 = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
+        const uint32_t off = (uint32_t)(ty * pitch + 4 * tx);
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-        const int r = ty + 16 * rr;
-        if (r < FT_ROWS) {
-            const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * pitch;
-            if (inner_x) {
-                lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
-                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
-            } else {
-                for (int c = tx; c < FT_WORDS; c += 16) {
-                    const int gx = x0 - 4 + 4 * c;
-                    uint32_t v = 0;
+        for (int rr = 0; rr < 3; rr++) {
+            const int r = ty + 16 * rr;
+            if (r < FT_ROWS) {
+                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)(16 * rr * pitch));
+                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)(16 * rr * pitch) + 64);
+            }
+        }
+    } else {
 #pragma unroll
-                    for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
-                    lds[r][c] = v;
+        for (int rr = 0; rr < 3; rr++) {
+            const int r = ty + 16 * rr;
+            if (r < FT_ROWS) {
+                const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * pitch;
+                if (inner_x) {
+                    lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
+                    if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
+                } else {
+                    for (int c = tx; c < FT_WORDS; c += 16) {
+                        const int gx = x0 - 4 + 4 * c;
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
+                        lds[r][c] = v;
+                    }
                 }
             }
         }
