@@ -150,7 +150,6 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
                                                     const ss_rtab *__restrict__ rtab, int level)
 {
     __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
-    __shared__ uint32_t hbuf[RS_ROWS][SS_TILE_W / 2]; /* horizontal results, two u16 per word */
     __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
@@ -173,37 +172,27 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     }
     __syncthreads();
 
-    /* Horizontal pass once per SOURCE row (as cv::resize's row buffers do): at scale 1.2 a source row
-     * feeds 1.7 destination rows, so this saves a third of the multiplies.  hbuf holds (h >> 4), u16. */
-    const int n_src = gy1 - gy0 + 1; /* <= RS_ROWS */
-    {
-        const int q = threadIdx.x & 31; /* column pair 2q, 2q + 1 */
-        const ss_rtab ra = xt[2 * q], rb = xt[2 * q + 1];
-        for (int r = threadIdx.x >> 5; r < n_src; r += 8) {
-            const uint8_t *l = (const uint8_t *)&lds[r][0] - gx0;
-            const uint32_t ha = (uint32_t)(l[ra.s0] * ra.a0 + l[ra.s1] * ra.a1) >> 4;
-            const uint32_t hb = (uint32_t)(l[rb.s0] * rb.a0 + l[rb.s1] * rb.a1) >> 4;
-            hbuf[r][q] = ha | (hb << 16);
-        }
-    }
-    __syncthreads();
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int dx4 = x0 + 4 * tx;
     if (dx4 >= D.w) return;
+    ss_rtab rx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rx[i] = xt[4 * tx + i];
 #pragma unroll
     for (int rr = 0; rr < RS_TILE_H / 16; rr++) {
         const int ly = ty + 16 * rr, dy = y0 + ly;
         if (dy >= D.h) break;
         const ss_rtab ry = yt[ly];
-        const uint32_t *h0 = &hbuf[ry.s0 - gy0][2 * tx], *h1 = &hbuf[ry.s1 - gy0][2 * tx];
-        const uint32_t b0 = (uint32_t)ry.a0, b1 = (uint32_t)ry.a1;
+        const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
+        const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
+        const int b0 = ry.a0, b1 = ry.a1;
         uint32_t out = 0;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t p0 = h0[i], p1 = h1[i];
-            const uint32_t va = (((b0 * (p0 & 0xFFFFu)) >> 16) + ((b1 * (p1 & 0xFFFFu)) >> 16) + 2) >> 2;
-            const uint32_t vb = (((b0 * (p0 >> 16)) >> 16) + ((b1 * (p1 >> 16)) >> 16) + 2) >> 2;
-            out |= ((va & 0xFFu) | ((vb & 0xFFu) << 8)) << (16 * i);
+        for (int i = 0; i < 4; i++) {
+            const int h0 = l0[rx[i].s0] * rx[i].a0 + l0[rx[i].s1] * rx[i].a1;
+            const int h1 = l1[rx[i].s0] * rx[i].a0 + l1[rx[i].s1] * rx[i].a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            out |= ((uint32_t)v & 0xFFu) << (8 * i);
         }
         *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
     }
@@ -1313,24 +1302,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     /* IC_Angle: the 31-row patch around the keypoint is staged in LDS as aligned dwords
      * (5 coalesced loads per lane instead of 16 byte gathers); lane = (row, half) of the disc */
     __shared__ uint32_t patch_all[4][31][10];
-    /* ... and so is the 37 x 37 window of the blurred level the steered pattern can reach (|offset| <= 18):
-     * both sets of loads are in flight together, and the 512 samples become LDS byte reads instead of
-     * global gathers that touch up to 37 lines per instruction */
-    __shared__ uint32_t bpatch_all[4][37][10];
     uint32_t(*patch)[10] = patch_all[threadIdx.x >> 6];
-    uint32_t(*bpatch)[10] = bpatch_all[threadIdx.x >> 6];
     const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
-    const int bx0 = (kx - 18) & ~3;
     {
         const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
         for (int idx = lane; idx < 31 * 10; idx += WAVE) {
             const int r = idx / 10, c = idx - r * 10;
             patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
-        }
-        const uint8_t *b0 = blur + fb + (size_t)(ky - 18) * pitch + bx0;
-        for (int idx = lane; idx < 37 * 10; idx += WAVE) {
-            const int r = idx / 10, c = idx - r * 10;
-            bpatch[r][c] = *(const uint32_t *)(b0 + (size_t)r * pitch + 4 * c);
         }
     }
     wave_sync();
@@ -1358,7 +1336,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     ss_sincosf_deg(angle, &b, &a);
 
     /* steered rBRIEF */
-    const uint8_t *center = (const uint8_t *)&bpatch[18][0] + (kx - bx0);
+    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx;
     uint64_t words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1369,7 +1347,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * 40 + c0], t1 = center[r1 * 40 + c1];
+        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
         words[k] = __ballot(t0 < t1);
     }
     if (lane == 0) {
