@@ -258,6 +258,44 @@ def test_batch_device_strides_and_alignments(oracle, w, stride, offset):
         assert got[b][0].tobytes() == okps.tobytes() and np.array_equal(got[b][1], odesc)
 
 
+def test_random_geometries_and_contents_vs_oracle(oracle):
+    """Seeded sweep over image sizes, feature counts, level counts, scale factors and contents (textured,
+    half flat, low contrast, noise): every tile / cell-window / bucket geometry the kernels index blindly is
+    exercised against the oracle, bit for bit."""
+    rng = np.random.default_rng(20261004)
+    checked = 0
+    for case in range(28):
+        w, h = int(rng.integers(200, 900)), int(rng.integers(170, 700))
+        nl = int(rng.integers(2, 9))
+        scale = float(rng.choice([1.2, 1.25, 1.5]))
+        nf = int(rng.integers(80, 1500))
+        img = synth.frame(100 + case, w, h).astype(np.int32)
+        kind = case % 4
+        if kind == 1:
+            img[:, : w // 2] = 128  # half flat: empty cells next to busy ones
+        elif kind == 2:
+            img = 120 + (img - 120) // 6  # low contrast: the minTh retry everywhere
+        elif kind == 3:
+            img = img + rng.integers(-25, 26, size=img.shape)  # heavy noise: many corners per tile
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        p = oracle.default_params(n_features=nf, n_levels=nl, scale_factor=scale)
+        try:
+            okps, odesc, ocounts = oracle.extract(img, p)
+        except (ValueError, RuntimeError):
+            # too small for this many levels: the product refuses it too, loudly
+            with binding.OrbContext(0, n_features=nf, n_levels=nl, scale_factor=scale) as ctx:
+                with pytest.raises(binding.OrbError) as e:
+                    ctx.extract(img)
+            assert e.value.code == binding.SS_ERR_TOO_SMALL, (case, w, h, nl, scale)
+            continue
+        with binding.OrbContext(0, n_features=nf, n_levels=nl, scale_factor=scale) as ctx:
+            kps, desc, counts = ctx.extract(img)
+        assert np.array_equal(counts, ocounts), (case, w, h, nf, nl, scale)
+        assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc), (case, w, h, nf, nl, scale)
+        checked += 1
+    assert checked >= 15
+
+
 def test_full_size_properties_metric_config():
     """BASELINE.json metric config (1280x720, 2000 kp): size-independent properties."""
     img = synth.frame(30, 1280, 720)
