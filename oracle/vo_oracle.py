@@ -6,10 +6,11 @@ cpu_baseline leg.  PARITY UNPINNED: the reference ships no ORB-SLAM3 source, tes
 descriptions, for a bounded monocular front-end (no keyframes, local mapping, loop closing):
 
   undistort      Frame::UndistortKeyPoints = cv::undistortPoints, 5 fixed-point iterations
-  two_view       TwoViewReconstruction, fundamental branch: Normalize, ComputeF21 (8-point + rank 2),
-                 CheckFundamental (chi2 3.841 / score 5.991, sigma 1), 200 RANSAC rounds, ReconstructF
-                 (E = K^T F K, DecomposeE, 4 x CheckRT with th2 = 4, minTriangulated 50, minParallax 1
-                 degree, second best < 0.7 best)
+  two_view       TwoViewReconstruction: Normalize; ComputeH21 (DLT) + CheckHomography (chi2 5.991) and
+                 ComputeF21 (8-point + rank 2) + CheckFundamental (chi2 3.841 / score 5.991) on the same 200
+                 RANSAC sets; RH = SH / (SH + SF) > 0.45 -> ReconstructH (Faugeras-Lustman, 8 hypotheses,
+                 second best < 0.75 best, > 0.9 N, > 50) else ReconstructF (E = K^T F K, DecomposeE, 4
+                 hypotheses, second best < 0.7 best); CheckRT with th2 = 4, minParallax 1 degree
   pose_only      Optimizer::PoseOptimization: 4 rounds x 10 Gauss-Newton steps (lambda 1e-6 damping),
                  Huber delta sqrt(5.991) in the first two rounds, outliers at chi2 > 5.991
   two_view_ba    Optimizer::GlobalBundleAdjustemnt(map, 20) on the two initial keyframes: camera 1 fixed,
@@ -29,6 +30,9 @@ import math
 import numpy as np
 
 MASK64 = (1 << 64) - 1
+# homography if SH / (SH + SF) exceeds it.  ORB-SLAM2: 0.40; ORB-SLAM3: `if(RH>0.50) // if(RH>0.40)` under the comment
+# "(0.40-0.45)"; a planar scene scores ~0.49, so 0.50 would never take the homography: 0.45 (csrc/ss_track.cpp)
+RH_THRESHOLD = 0.45
 
 
 class Camera:
@@ -159,17 +163,73 @@ def _check_rt(cam, R, t, x1, x2, inl, th2):
     return n_good, p3d, good, parallax
 
 
-def two_view(cam: Camera, x1, x2):
-    """-> (R, t, triangulated mask, pts3d) or None"""
+def _compute_h21(p1, p2):
+    u1, v1, u2, v2 = p1[:, 0], p1[:, 1], p2[:, 0], p2[:, 1]
+    z, o = np.zeros_like(u1), np.ones_like(u1)
+    ra = np.stack([z, z, z, -u1, -v1, -o, v2 * u1, v2 * v1, v2], axis=1)
+    rb = np.stack([u1, v1, o, z, z, z, -u2 * u1, -u2 * v1, -u2], axis=1)
+    A = np.empty((2 * len(u1), 9))
+    A[0::2], A[1::2] = ra, rb
+    _, _, vt = np.linalg.svd(A)
+    return vt[8].reshape(3, 3)
+
+
+def _check_homography(H21, H12, x1, x2):
+    th = 5.991
+    h1 = np.concatenate([x1, np.ones((len(x1), 1))], axis=1)
+    h2 = np.concatenate([x2, np.ones((len(x2), 1))], axis=1)
+    a = h2 @ H12.T
+    a = a[:, :2] / a[:, 2:3]
+    chi1 = ((x1 - a) ** 2).sum(axis=1)
+    b = h1 @ H21.T
+    b = b[:, :2] / b[:, 2:3]
+    chi2 = ((x2 - b) ** 2).sum(axis=1)
+    ok1, ok2 = chi1 <= th, chi2 <= th
+    score = 0.0
+    for c1, o1, c2, o2 in zip(chi1, ok1, chi2, ok2):
+        if o1:
+            score += th - c1
+        if o2:
+            score += th - c2
+    return score, ok1 & ok2
+
+
+def _pick(cam, hyps, x1, x2, inl, N, homography):
+    res = [_check_rt(cam, R, t, x1, x2, inl, 4.0) for R, t in hyps]
+    goods = [r[0] for r in res]
+    best_good = max(goods)
+    if best_good <= 0:
+        return None
+    k = goods.index(best_good)
+    second = max([g for i, g in enumerate(goods) if i != k] + [0])
+    parallax = res[k][3]
+    if homography:
+        if not (second < 0.75 * best_good and parallax >= 1.0 and best_good > 50 and best_good > 0.9 * N):
+            return None
+    else:
+        n_similar = sum(g > 0.7 * best_good for g in goods)
+        if best_good < max(int(0.9 * N), 50) or n_similar > 1 or not parallax > 1.0:
+            return None
+    return hyps[k][0], hyps[k][1], res[k][2], res[k][1]
+
+
+def two_view(cam: Camera, x1, x2, return_model=False):
+    """-> (R, t, triangulated mask, pts3d) or None   [, model: 1 fundamental, 2 homography]"""
     x1 = np.asarray(x1, np.float64).reshape(-1, 2)
     x2 = np.asarray(x2, np.float64).reshape(-1, 2)
     n = len(x1)
+
+    def ret(r, model):
+        return (r, model) if return_model else r
+
     if n < 8:
-        return None
+        return ret(None, 0)
     n1, T1 = _normalize(x1)
     n2, T2 = _normalize(x2)
+    T2inv = np.linalg.inv(T2)
     rng = _Lcg()
-    best_score, best_F, best_inl = -1.0, None, None
+    best_sf, best_F, inl_f = -1.0, None, None
+    best_sh, best_H, inl_h = -1.0, None, None
     for _ in range(200):
         avail = list(range(n))
         idx = []
@@ -178,15 +238,48 @@ def two_view(cam: Camera, x1, x2):
             idx.append(avail[r])
             avail[r] = avail[-1]
             avail.pop()
-        Fn = _compute_f21(n1[idx], n2[idx])
-        F = T2.T @ Fn @ T1
-        score, inl = _check_fundamental(F, x1, x2)
-        if score > best_score:
-            best_score, best_F, best_inl = score, F, inl
-    N = int(best_inl.sum())
-    if N < 8:
-        return None
+        H = T2inv @ _compute_h21(n1[idx], n2[idx]) @ T1
+        if abs(np.linalg.det(H)) > 1e-300:
+            sh, ih = _check_homography(H, np.linalg.inv(H), x1, x2)
+            if sh > best_sh:
+                best_sh, best_H, inl_h = sh, H, ih
+        F = T2.T @ _compute_f21(n1[idx], n2[idx]) @ T1
+        sf, i_f = _check_fundamental(F, x1, x2)
+        if sf > best_sf:
+            best_sf, best_F, inl_f = sf, F, i_f
     K = cam.K
+    if best_sh > 0 and best_sh / (best_sh + max(best_sf, 0.0)) > RH_THRESHOLD:
+        N = int(inl_h.sum())
+        if N < 8:
+            return ret(None, 2)
+        A = np.linalg.inv(K) @ best_H @ K
+        U, w, Vt = np.linalg.svd(A)
+        V = Vt.T
+        sgn = np.linalg.det(U) * np.linalg.det(Vt)
+        d1, d2, d3 = w
+        if d1 / d2 < 1.00001 or d2 / d3 < 1.00001:
+            return ret(None, 2)
+        aux1 = math.sqrt((d1 * d1 - d2 * d2) / (d1 * d1 - d3 * d3))
+        aux3 = math.sqrt((d2 * d2 - d3 * d3) / (d1 * d1 - d3 * d3))
+        x1s, x3s = [aux1, aux1, -aux1, -aux1], [aux3, -aux3, aux3, -aux3]
+        root = math.sqrt((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3))
+        st0, ct = root / ((d1 + d3) * d2), (d2 * d2 + d1 * d3) / ((d1 + d3) * d2)
+        sp0, cp = root / ((d1 - d3) * d2), (d1 * d3 - d2 * d2) / ((d1 - d3) * d2)
+        sts, sps = [st0, -st0, -st0, st0], [sp0, -sp0, -sp0, sp0]
+        hyps = []
+        for i in range(4):  # d' = +d2
+            Rp = np.array([[ct, 0, -sts[i]], [0, 1, 0], [sts[i], 0, ct]])
+            tt = U @ (np.array([x1s[i], 0, -x3s[i]]) * (d1 - d3))
+            hyps.append((sgn * U @ Rp @ Vt, tt / np.linalg.norm(tt)))
+        for i in range(4):  # d' = -d2
+            Rp = np.array([[cp, 0, sps[i]], [0, -1, 0], [sps[i], 0, -cp]])
+            tt = U @ (np.array([x1s[i], 0, x3s[i]]) * (d1 + d3))
+            hyps.append((sgn * U @ Rp @ Vt, tt / np.linalg.norm(tt)))
+        _ = V
+        return ret(_pick(cam, hyps, x1, x2, inl_h, N, True), 2)
+    N = int(inl_f.sum())
+    if N < 8:
+        return ret(None, 1)
     E = K.T @ best_F @ K
     u, _, vt = np.linalg.svd(E)
     t = u[:, 2] / np.linalg.norm(u[:, 2])
@@ -198,18 +291,7 @@ def two_view(cam: Camera, x1, x2):
     if np.linalg.det(R2) < 0:
         R2 = -R2
     # the sign of a singular vector is arbitrary: (R1, R2, t, -t) as a SET is what is defined
-    hyps = [(R1, t), (R2, t), (R1, -t), (R2, -t)]
-    res = [_check_rt(cam, R, tt, x1, x2, best_inl, 4.0) for R, tt in hyps]
-    goods = [r[0] for r in res]
-    max_good = max(goods)
-    n_min_good = max(int(0.9 * N), 50)
-    n_similar = sum(g > 0.7 * max_good for g in goods)
-    if max_good < n_min_good or n_similar > 1:
-        return None
-    k = goods.index(max_good)
-    if res[k][3] <= 1.0:
-        return None
-    return hyps[k][0], hyps[k][1], res[k][2], res[k][1]
+    return ret(_pick(cam, [(R1, t), (R2, t), (R1, -t), (R2, -t)], x1, x2, inl_f, N, False), 1)
 
 
 def _se3_exp(d):

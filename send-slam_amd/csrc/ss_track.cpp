@@ -98,15 +98,29 @@ void svd3(const double *M, double *U, double *s, double *V)
         s[k] = std::sqrt(ev[src] > 0 ? ev[src] : 0.0);
         for (int i = 0; i < 3; i++) V[3 * i + k] = Ve[3 * i + src];
     }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 3; k++) {
         double u[3];
         for (int i = 0; i < 3; i++) u[i] = M[3 * i] * V[k] + M[3 * i + 1] * V[3 + k] + M[3 * i + 2] * V[6 + k];
         const double nrm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (k == 2 && !(nrm > 1e-9 * s[0])) { /* rank 2: complete the basis */
+            U[2] = U[3 * 1 + 0] * U[3 * 2 + 1] - U[3 * 2 + 0] * U[3 * 1 + 1];
+            U[5] = U[3 * 2 + 0] * U[3 * 0 + 1] - U[3 * 0 + 0] * U[3 * 2 + 1];
+            U[8] = U[3 * 0 + 0] * U[3 * 1 + 1] - U[3 * 1 + 0] * U[3 * 0 + 1];
+            break;
+        }
         for (int i = 0; i < 3; i++) U[3 * i + k] = nrm > 0 ? u[i] / nrm : (i == k ? 1.0 : 0.0);
     }
-    U[2] = U[3 * 1 + 0] * U[3 * 2 + 1] - U[3 * 2 + 0] * U[3 * 1 + 1];
-    U[5] = U[3 * 2 + 0] * U[3 * 0 + 1] - U[3 * 0 + 0] * U[3 * 2 + 1];
-    U[8] = U[3 * 0 + 0] * U[3 * 1 + 1] - U[3 * 1 + 0] * U[3 * 0 + 1];
+}
+
+bool inv3_full(const double *m, double *o)
+{
+    const double d = det3(m);
+    if (!(std::fabs(d) > 1e-300)) return false;
+    const double id = 1.0 / d;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
 }
 
 struct lcg { /* deterministic sampler (the reference seeds rand() with 0; any fixed generator serves) */
@@ -174,6 +188,39 @@ double check_fundamental(const double *F, int n, const double *x1, const double 
         const double num1 = a1 * u1 + b1 * v1 + c1;
         const double chi2 = num1 * num1 / (a1 * a1 + b1 * b1) * inv_sigma2;
         if (chi2 > th) in = false; else score += th_score - chi2;
+        inl[i] = in;
+    }
+    return score;
+}
+
+void compute_h21(const double *p1, const double *p2, const int idx[8], double H[9])
+{
+    double A[16 * 9];
+    for (int k = 0; k < 8; k++) {
+        const double u1 = p1[2 * idx[k]], v1 = p1[2 * idx[k] + 1], u2 = p2[2 * idx[k]], v2 = p2[2 * idx[k] + 1];
+        double *r = A + 18 * k;
+        r[0] = 0; r[1] = 0; r[2] = 0; r[3] = -u1; r[4] = -v1; r[5] = -1; r[6] = v2 * u1; r[7] = v2 * v1; r[8] = v2;
+        r[9] = u1; r[10] = v1; r[11] = 1; r[12] = 0; r[13] = 0; r[14] = 0; r[15] = -u2 * u1; r[16] = -u2 * v1; r[17] = -u2;
+    }
+    null_vector(16, 9, A, H);
+}
+
+double check_homography(const double *H21, const double *H12, int n, const double *x1, const double *x2, std::vector<uint8_t> &inl)
+{
+    const double th = 5.991, inv_sigma2 = 1.0;
+    double score = 0;
+    inl.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        bool in = true;
+        const double w21 = 1.0 / (H12[6] * u2 + H12[7] * v2 + H12[8]); /* x2 seen in image 1 */
+        const double a = (H12[0] * u2 + H12[1] * v2 + H12[2]) * w21, b = (H12[3] * u2 + H12[4] * v2 + H12[5]) * w21;
+        const double chi1 = ((u1 - a) * (u1 - a) + (v1 - b) * (v1 - b)) * inv_sigma2;
+        if (chi1 > th) in = false; else score += th - chi1;
+        const double w12 = 1.0 / (H21[6] * u1 + H21[7] * v1 + H21[8]); /* x1 seen in image 2 */
+        const double cc = (H21[0] * u1 + H21[1] * v1 + H21[2]) * w12, d = (H21[3] * u1 + H21[4] * v1 + H21[5]) * w12;
+        const double chi2 = ((u2 - cc) * (u2 - cc) + (v2 - d) * (v2 - d)) * inv_sigma2;
+        if (chi2 > th) in = false; else score += th - chi2;
         inl[i] = in;
     }
     return score;
@@ -319,23 +366,70 @@ void sst_undistort(const sst_camera &c, int n, const float *xy_in, double *xy_ou
     }
 }
 
+namespace {
+
+/* picks the hypothesis CheckRT likes best, with ReconstructF's / ReconstructH's acceptance rule */
+int pick_hypothesis(const sst_camera &c, int n_hyp, const double (*Rs)[9], const double (*ts)[3], int n, const double *x1,
+                    const double *x2, const std::vector<uint8_t> &inl, int N, bool homography, double R[9], double t[3],
+                    std::vector<uint8_t> &triangulated, std::vector<double> &pts3d)
+{
+    int best = -1, best_good = 0, second_good = 0, n_similar = 0;
+    double best_parallax = -1;
+    std::vector<double> p3d, best_p3d;
+    std::vector<uint8_t> good, best_flags;
+    std::vector<int> goods((size_t)n_hyp);
+    for (int k = 0; k < n_hyp; k++) {
+        double parallax;
+        const int g = check_rt(c, Rs[k], ts[k], n, x1, x2, inl, 4.0, p3d, good, parallax);
+        goods[k] = g;
+        if (g > best_good) {
+            second_good = best_good;
+            best_good = g;
+            best = k;
+            best_parallax = parallax;
+            best_p3d = p3d;
+            best_flags = good;
+        } else if (g > second_good) {
+            second_good = g;
+        }
+    }
+    if (best < 0) return 0;
+    if (homography) {
+        if (!(second_good < 0.75 * best_good && best_parallax >= 1.0 && best_good > 50 && best_good > 0.9 * N)) return 0;
+    } else {
+        for (int k = 0; k < n_hyp; k++) n_similar += goods[k] > 0.7 * best_good;
+        if (best_good < std::max((int)(0.9 * N), 50) || n_similar > 1 || !(best_parallax > 1.0)) return 0;
+    }
+    memcpy(R, Rs[best], sizeof(double) * 9);
+    memcpy(t, ts[best], sizeof(double) * 3);
+    triangulated = best_flags;
+    pts3d = best_p3d;
+    int cnt = 0;
+    for (uint8_t b : triangulated) cnt += b;
+    return cnt;
+}
+
+} // namespace
+
 int sst_two_view(const sst_camera &c, int n, const double *x1, const double *x2, double R[9], double t[3],
-                 std::vector<uint8_t> &triangulated, std::vector<double> &pts3d)
+                 std::vector<uint8_t> &triangulated, std::vector<double> &pts3d, int *model)
 {
     triangulated.assign((size_t)n, 0);
     pts3d.assign((size_t)3 * n, 0.0);
+    if (model) *model = 0;
     if (n < 8) return 0;
     std::vector<double> n1, n2;
-    double T1[9], T2[9], T2t[9];
+    double T1[9], T2[9], T2t[9], T2inv[9];
     normalize_pts(n, x1, n1, T1);
     normalize_pts(n, x2, n2, T2);
     mat3_t(T2, T2t);
+    if (!inv3_full(T2, T2inv)) return 0;
 
-    /* FindFundamental: 200 RANSAC rounds of the normalised 8-point algorithm */
+    /* FindHomography and FindFundamental on the same 200 minimal sets (ORB-SLAM3 runs them side by side) */
     lcg rng{0x9E3779B97F4A7C15ull};
     std::vector<int> avail((size_t)n);
-    std::vector<uint8_t> inl, best_inl;
-    double best_score = -1, best_F[9] = {0};
+    std::vector<uint8_t> inl, best_inl_f, best_inl_h;
+    double best_sf = -1, best_sh = -1, best_F[9] = {0}, best_H[9] = {0};
     for (int it = 0; it < 200; it++) {
         for (int i = 0; i < n; i++) avail[i] = i;
         int idx[8], na = n;
@@ -345,66 +439,106 @@ int sst_two_view(const sst_camera &c, int n, const double *x1, const double *x2,
             avail[r] = avail[na - 1];
             na--;
         }
-        double Fn[9], tmp[9], F[9];
-        compute_f21(n1.data(), n2.data(), idx, Fn);
-        mat3_mul(T2t, Fn, tmp);
-        mat3_mul(tmp, T1, F);
-        const double score = check_fundamental(F, n, x1, x2, inl);
-        if (score > best_score) {
-            best_score = score;
-            best_inl = inl;
-            memcpy(best_F, F, sizeof(F));
+        double Mn[9], tmp[9], M[9], Minv[9];
+        compute_h21(n1.data(), n2.data(), idx, Mn);
+        mat3_mul(T2inv, Mn, tmp);
+        mat3_mul(tmp, T1, M);
+        if (inv3_full(M, Minv)) {
+            const double sh = check_homography(M, Minv, n, x1, x2, inl);
+            if (sh > best_sh) {
+                best_sh = sh;
+                best_inl_h = inl;
+                memcpy(best_H, M, sizeof(M));
+            }
+        }
+        compute_f21(n1.data(), n2.data(), idx, Mn);
+        mat3_mul(T2t, Mn, tmp);
+        mat3_mul(tmp, T1, M);
+        const double sf = check_fundamental(M, n, x1, x2, inl);
+        if (sf > best_sf) {
+            best_sf = sf;
+            best_inl_f = inl;
+            memcpy(best_F, M, sizeof(M));
         }
     }
-    int N = 0;
-    for (uint8_t b : best_inl) N += b;
-    if (N < 8) return 0;
-
-    /* ReconstructF */
     const double K[9] = {c.fx, 0, c.cx, 0, c.fy, c.cy, 0, 0, 1};
-    double Kt[9], tmp[9], E[9];
+    double tmp[9];
+    /* Model selection: RH = SH / (SH + SF) above the threshold -> homography.  ORB-SLAM2 uses 0.40; ORB-SLAM3's
+     * source reads `if(RH>0.50) // if(RH>0.40)` under the comment "depending on the ratio (0.40-0.45)".  A
+     * planar scene scores RH ~ 0.49 (a line distance is never larger than a point distance, so SF >= SH whenever
+     * both models fit), i.e. at 0.50 it would be handed to the degenerate fundamental matrix: 0.45 is used. */
+    const bool use_h = best_sh > 0 && best_sh / (best_sh + (best_sf > 0 ? best_sf : 0.0)) > SST_RH_THRESHOLD;
+    if (use_h) {
+        if (model) *model = 2;
+        int N = 0;
+        for (uint8_t b : best_inl_h) N += b;
+        if (N < 8) return 0;
+        /* ReconstructH: Faugeras & Lustman, eight hypotheses from the SVD of K^-1 H K */
+        double Kinv[9], A[9], U[9], w[3], V[9], Vt[9];
+        if (!inv3_full(K, Kinv)) return 0;
+        mat3_mul(Kinv, best_H, tmp);
+        mat3_mul(tmp, K, A);
+        svd3(A, U, w, V);
+        mat3_t(V, Vt);
+        const double sgn = det3(U) * det3(Vt);
+        const double d1 = w[0], d2 = w[1], d3 = w[2];
+        if (d1 / d2 < 1.00001 || d2 / d3 < 1.00001) return 0;
+        const double aux1 = std::sqrt((d1 * d1 - d2 * d2) / (d1 * d1 - d3 * d3)), aux3 = std::sqrt((d2 * d2 - d3 * d3) / (d1 * d1 - d3 * d3));
+        const double x1s[4] = {aux1, aux1, -aux1, -aux1}, x3s[4] = {aux3, -aux3, aux3, -aux3};
+        const double aux_st = std::sqrt((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 + d3) * d2);
+        const double ct = (d2 * d2 + d1 * d3) / ((d1 + d3) * d2);
+        const double st[4] = {aux_st, -aux_st, -aux_st, aux_st};
+        const double aux_sp = std::sqrt((d1 * d1 - d2 * d2) * (d2 * d2 - d3 * d3)) / ((d1 - d3) * d2);
+        const double cp = (d1 * d3 - d2 * d2) / ((d1 - d3) * d2);
+        const double sp[4] = {aux_sp, -aux_sp, -aux_sp, aux_sp};
+        double Rs[8][9], ts[8][3];
+        for (int i = 0; i < 8; i++) {
+            const int j = i & 3;
+            const bool pos = i < 4; /* d' = +d2, then d' = -d2 */
+            const double Rp[9] = {pos ? ct : cp, 0, pos ? -st[j] : sp[j], 0, pos ? 1.0 : -1.0, 0, pos ? st[j] : sp[j], 0, pos ? ct : -cp};
+            mat3_mul(U, Rp, tmp);
+            mat3_mul(tmp, Vt, Rs[i]);
+            for (double &v : Rs[i]) v *= sgn;
+            const double scale = pos ? d1 - d3 : d1 + d3;
+            const double tp[3] = {x1s[j] * scale, 0, (pos ? -x3s[j] : x3s[j]) * scale};
+            double tt[3], nrm = 0;
+            for (int r = 0; r < 3; r++) {
+                tt[r] = U[3 * r] * tp[0] + U[3 * r + 1] * tp[1] + U[3 * r + 2] * tp[2];
+                nrm += tt[r] * tt[r];
+            }
+            nrm = std::sqrt(nrm);
+            for (int r = 0; r < 3; r++) ts[i][r] = tt[r] / nrm;
+        }
+        return pick_hypothesis(c, 8, Rs, ts, n, x1, x2, best_inl_h, N, true, R, t, triangulated, pts3d);
+    }
+
+    if (model) *model = 1;
+    int N = 0;
+    for (uint8_t b : best_inl_f) N += b;
+    if (N < 8) return 0;
+    /* ReconstructF */
+    double Kt[9], E[9];
     mat3_t(K, Kt);
     mat3_mul(Kt, best_F, tmp);
     mat3_mul(tmp, K, E);
-    double U[9], s[3], V[9], Vt[9];
-    svd3(E, U, s, V);
+    double U[9], sv[3], V[9], Vt[9];
+    svd3(E, U, sv, V);
     mat3_t(V, Vt);
     double tt[3] = {U[2], U[5], U[8]};
     const double tn = std::sqrt(tt[0] * tt[0] + tt[1] * tt[1] + tt[2] * tt[2]);
     for (double &v : tt) v /= tn;
     const double W[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
-    double R1[9], R2[9];
+    double Rs[4][9], ts[4][3];
     mat3_mul(U, W, tmp);
-    mat3_mul(tmp, Vt, R1);
+    mat3_mul(tmp, Vt, Rs[0]);
     mat3_mul(U, Wt, tmp);
-    mat3_mul(tmp, Vt, R2);
-    if (det3(R1) < 0) for (double &v : R1) v = -v;
-    if (det3(R2) < 0) for (double &v : R2) v = -v;
-    const double t1[3] = {tt[0], tt[1], tt[2]}, t2[3] = {-tt[0], -tt[1], -tt[2]};
-    const double *Rs[4] = {R1, R2, R1, R2};
-    const double *ts[4] = {t1, t1, t2, t2};
-    std::vector<double> p3d[4];
-    std::vector<uint8_t> good[4];
-    int n_good[4];
-    double parallax[4];
-    for (int k = 0; k < 4; k++) n_good[k] = check_rt(c, Rs[k], ts[k], n, x1, x2, best_inl, 4.0, p3d[k], good[k], parallax[k]);
-    const int max_good = std::max(std::max(n_good[0], n_good[1]), std::max(n_good[2], n_good[3]));
-    const int n_min_good = std::max((int)(0.9 * N), 50);
-    int n_similar = 0;
-    for (int k = 0; k < 4; k++) n_similar += n_good[k] > 0.7 * max_good;
-    if (max_good < n_min_good || n_similar > 1) return 0;
-    for (int k = 0; k < 4; k++) {
-        if (n_good[k] != max_good) continue;
-        if (parallax[k] <= 1.0) return 0;
-        memcpy(R, Rs[k], sizeof(double) * 9);
-        memcpy(t, ts[k], sizeof(double) * 3);
-        triangulated = good[k];
-        pts3d = p3d[k];
-        int cnt = 0;
-        for (uint8_t b : triangulated) cnt += b;
-        return cnt;
-    }
-    return 0;
+    mat3_mul(tmp, Vt, Rs[1]);
+    if (det3(Rs[0]) < 0) for (double &v : Rs[0]) v = -v;
+    if (det3(Rs[1]) < 0) for (double &v : Rs[1]) v = -v;
+    memcpy(Rs[2], Rs[0], sizeof(Rs[0]));
+    memcpy(Rs[3], Rs[1], sizeof(Rs[1]));
+    for (int r = 0; r < 3; r++) { ts[0][r] = ts[1][r] = tt[r]; ts[2][r] = ts[3][r] = -tt[r]; }
+    return pick_hypothesis(c, 4, Rs, ts, n, x1, x2, best_inl_f, N, false, R, t, triangulated, pts3d);
 }
 
 int sst_pose_only(int n, const double *pts3d, const double *obs, const double *inv_sigma2, const sst_camera &c,

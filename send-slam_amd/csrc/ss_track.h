@@ -8,9 +8,11 @@
  * is out of scope; this is a monocular visual-odometry front-end made of the same building blocks
  * (restated from the published algorithms, parity unpinned like the rest):
  *   sst_undistort        Frame::UndistortKeyPoints = cv::undistortPoints (k1 k2 p1 p2, 5 iterations)
- *   sst_two_view         TwoViewReconstruction (fundamental-matrix branch): normalised 8-point in
- *                        200 RANSAC rounds, symmetric-transfer chi2 score, E = K^T F K, four (R, t)
- *                        hypotheses, linear triangulation, cheirality / reprojection / parallax checks
+ *   sst_two_view         TwoViewReconstruction: homography (DLT) and fundamental matrix (normalised
+ *                        8-point) on the same 200 RANSAC sets, chi2 scores, model choice by
+ *                        SH / (SH + SF) > 0.45; ReconstructF (E = K^T F K, four hypotheses) or ReconstructH
+ *                        (Faugeras-Lustman, eight hypotheses); linear triangulation, cheirality /
+ *                        reprojection / parallax checks
  *   sst_pose_only        Optimizer::PoseOptimization (g2o EdgeSE3ProjectXYZOnlyPose): 4 x 10 damped
  *                        Gauss-Newton steps, Huber sqrt(5.991), outliers at chi2 > 5.991
  *   sst_triangulate      linear two-view triangulation (DLT)
@@ -23,6 +25,8 @@
 #include <cstdint>
 #include <vector>
 
+#define SST_RH_THRESHOLD 0.45 /* homography if SH / (SH + SF) exceeds it: see sst_two_view */
+
 struct sst_camera {
     double fx, fy, cx, cy, k1, k2, p1, p2;
 };
@@ -34,7 +38,7 @@ void sst_undistort(const sst_camera &c, int n, const float *xy_in /* stride 2 */
  * reference, |t| = 1), triangulated[n] flags and pts3d (reference frame) and returns the number of
  * triangulated points; 0 if the pair does not reconstruct (too little parallax, ambiguous, < 50). */
 int sst_two_view(const sst_camera &c, int n, const double *x1, const double *x2, double R[9], double t[3],
-                 std::vector<uint8_t> &triangulated, std::vector<double> &pts3d);
+                 std::vector<uint8_t> &triangulated, std::vector<double> &pts3d, int *model = nullptr /* 1 F, 2 H */);
 
 /* Two-view bundle adjustment (what Optimizer::GlobalBundleAdjustemnt does to the initial map of two
  * keyframes, CreateInitialMapMonocular): camera 1 fixed at the origin, camera 2 (R, t) and the n

@@ -11,11 +11,14 @@ extern "C" {
 
 void shim_undistort(const double *cam, int n, const float *xy, double *out) { sst_undistort(cam_of(cam), n, xy, out); }
 
+int shim_last_model = 0;
+int shim_two_view_model(void) { return shim_last_model; }
+
 int shim_two_view(const double *cam, int n, const double *x1, const double *x2, double *R, double *t, uint8_t *tri, double *p3d)
 {
     std::vector<uint8_t> tr;
     std::vector<double> p;
-    const int r = sst_two_view(cam_of(cam), n, x1, x2, R, t, tr, p);
+    const int r = sst_two_view(cam_of(cam), n, x1, x2, R, t, tr, p, &shim_last_model);
     if (n > 0) {
         memcpy(tri, tr.data(), (size_t)n);
         memcpy(p3d, p.data(), sizeof(double) * 3 * (size_t)n);

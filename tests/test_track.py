@@ -149,6 +149,114 @@ def test_two_view_ba_matches_oracle_and_improves_the_pose(shim, seed):
     assert r1 <= r0 + 0.02 and d1 <= d0 + 0.2 and r1 < 0.3 and d1 < 2.0
 
 
+def planar_case(seed, n=300, noise=0.3, outliers=0.08, lateral=True):
+    """Points on a plane seen from two cameras.  Two views of a plane admit two physical reconstructions
+    (Faugeras-Lustman: the roles of translation and plane normal swap); `lateral` = camera sliding roughly
+    parallel to a roughly fronto-parallel plane, where the twin solution puts the plane edge-on and fails
+    the positive-depth test, so the pair is decidable."""
+    rng = np.random.default_rng(seed)
+    tilt = 0.08 if lateral else 0.3
+    nrm = np.array([rng.uniform(-tilt, tilt), rng.uniform(-tilt, tilt), -1.0])
+    nrm /= np.linalg.norm(nrm)
+    d = -6.0
+    xy = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n)], axis=1)
+    z = (d - xy @ nrm[:2]) / nrm[2]
+    X = np.concatenate([xy, z[:, None]], axis=1)
+    if lateral:
+        R = rot(rng.normal(size=3), rng.uniform(0.3, 1.5))
+        t = np.array([rng.normal(), rng.normal(), 0.1 * rng.normal()])
+    else:
+        R = rot(rng.normal(size=3), rng.uniform(1, 5))
+        t = rng.normal(size=3)
+    t = t / np.linalg.norm(t) * 0.7
+    x1 = project(CAM, np.eye(3), np.zeros(3), X) + rng.normal(scale=noise, size=(n, 2))
+    x2 = project(CAM, R, t, X) + rng.normal(scale=noise, size=(n, 2))
+    bad = rng.random(n) < outliers
+    x2[bad] += rng.uniform(-50, 50, size=(int(bad.sum()), 2))
+    return X, R, t, np.ascontiguousarray(x1), np.ascontiguousarray(x2), bad
+
+
+@pytest.mark.parametrize("seed", [109, 115, 126, 129, 134, 135])
+def test_two_view_planar_scene_takes_the_homography_branch(shim, seed):
+    """A planar scene is degenerate for the fundamental matrix: RH = SH / (SH + SF) > 0.45 selects the homography
+    and ReconstructH (Faugeras-Lustman, 8 hypotheses) must return the true motion.  The seeds are the pairs of a
+    scan of 60 in which the twin solution loses more than a quarter of the points (one in eight: see
+    test_two_view_ambiguous_planar_pair_is_refused for the rest)."""
+    X, R_gt, t_gt, x1, x2, bad = planar_case(seed)
+    n_tri, R, t, tri, p3d = shim_two_view(shim, CAM, x1, x2)
+    assert shim.shim_two_view_model() == 2
+    ref, model = vo.two_view(CAM, x1, x2, return_model=True)
+    assert model == 2 and ref is not None and n_tri > 0
+    R_o, t_o, tri_o, p3d_o = ref
+    assert np.array_equal(tri, tri_o)
+    assert np.allclose(R, R_o, rtol=0, atol=TOL) and np.allclose(t, t_o, rtol=0, atol=TOL)
+    assert np.allclose(p3d[tri], p3d_o[tri], rtol=1e-5, atol=1e-6)
+    dR = R @ R_gt.T
+    assert math.degrees(math.acos(min(1.0, (np.trace(dR) - 1) / 2))) < 0.6
+    assert math.degrees(math.acos(min(1.0, float(t @ t_gt) / np.linalg.norm(t_gt)))) < 4.0
+    ok = tri & ~bad
+    assert ok.sum() > 0.8 * (~bad).sum()
+    scale = np.linalg.norm(t_gt)
+    assert np.median(np.linalg.norm(p3d[ok] * scale - X[ok], axis=1) / X[ok, 2]) < 0.06
+
+
+def test_two_view_ambiguous_planar_pair_is_refused(shim):
+    """A generic motion over a tilted plane leaves BOTH Faugeras-Lustman solutions in front of the cameras:
+    ReconstructH's `second best < 0.75 best` rule refuses the pair (a later frame decides), in both statements."""
+    X, R_gt, t_gt, x1, x2, bad = planar_case(51, lateral=False)
+    n_tri, R, t, tri, p3d = shim_two_view(shim, CAM, x1, x2)
+    assert shim.shim_two_view_model() == 2 and n_tri == 0
+    ref, model = vo.two_view(CAM, x1, x2, return_model=True)
+    assert model == 2 and ref is None
+
+
+def test_two_view_general_scene_takes_the_fundamental_branch(shim):
+    X, R_gt, t_gt, x1, x2, bad = two_view_case(2)
+    shim_two_view(shim, CAM, x1, x2)
+    assert shim.shim_two_view_model() == 1
+    assert vo.two_view(CAM, x1, x2, return_model=True)[1] == 1
+
+
+def test_tracker_initialises_on_a_planar_image_sequence(shim, oracle):
+    """synth.frame sequences are a fronto-parallel plane sliding by (3, -2) px per frame: only the homography
+    branch can initialise on them.  The camera then moves along (-3, +2, 0) at constant speed."""
+    import track_ref
+    w, h, seed = 640, 480, 31
+    sc = synth.scene(seed, w, h)
+    frames = [synth.frame_from_scene(sc, seed, w, h, t) for t in range(22)]
+    cam = vo.Camera(500.0, 500.0, 320.0, 240.0)
+    params = oracle.default_params(n_features=1000)
+
+    def extract(img):
+        kps, desc, _ = oracle.extract(img, params)
+        return kps, desc
+
+    prod, ref = ShimTracker(shim, cam, 1.2), vo.Tracker(cam, 1.2)
+    outs = run_sequence(frames, extract, lambda q, t: oracle.match(q, t, 50, 9, 10, False), [prod, ref])
+    prod.close()
+    states = [o[0]["state"] for o in outs]
+    assert 2 in states and states[-1] == 2 and 4 not in states
+    first_ok = states.index(2)
+    # the twin solution of the plane keeps > 75 % of the points until the baseline has grown to ~6 degrees of
+    # parallax: like ORB-SLAM on a poster, initialisation takes a while (frame 16 here)
+    assert 8 <= first_ok <= 19
+    for a, b in outs:
+        assert (a["state"], a["n_matches"], a["n_inliers"], a["n_map_points"]) == \
+               (b["state"], b["n_matches"], b["n_inliers"], b["n_map_points"])
+        assert np.allclose(a["position"], b["position"], rtol=0, atol=1e-6)
+        assert np.allclose(a["quaternion"], b["quaternion"], rtol=0, atol=1e-6)
+    pos = np.array([o[0]["position"] for o in outs[first_ok:]])
+    steps = np.arange(first_ok, len(outs))
+    direction = pos[-1] / np.linalg.norm(pos[-1])
+    want = np.array([-3.0, 2.0, 0.0]) / math.sqrt(13.0)
+    assert math.degrees(math.acos(min(1.0, float(direction @ want)))) < 6.0
+    speed = np.linalg.norm(pos, axis=1) / steps
+    assert np.abs(speed / speed.mean() - 1).max() < 0.08
+    # median depth 1 and a 3.6-px shift per frame at f = 500: |step| = 3.6 / 500
+    assert abs(speed.mean() - math.sqrt(13.0) / 500.0) < 0.1 * math.sqrt(13.0) / 500.0
+    assert max(np.abs(o[0]["quaternion"][:3]).max() for o in outs[first_ok:]) < 5e-3
+
+
 def test_two_view_refuses_degenerate_pairs(shim):
     X, R_gt, t_gt, x1, x2, bad = two_view_case(7, outliers=0.0)
     # no motion at all: no parallax -> no reconstruction
@@ -377,3 +485,45 @@ def test_parallax_sequence_is_what_it_says():
     assert np.array_equal(synth.parallax_frame(seed, w, h, 3), synth.parallax_frame(seed, w, h, 3, sc=sc))
     with pytest.raises(ValueError):
         synth.parallax_frame(seed, w, h, 32)
+
+
+TRACK_GOLDEN = sorted(__import__("glob").glob(os.path.join(ROOT, "tests", "golden", "track", "*.npz")))
+
+
+def _golden_frames(z):
+    seed, w, h = int(z["seed"]), int(z["width"]), int(z["height"])
+    sc = synth.scene(seed, w, h)
+    frames = [synth.parallax_frame(seed, w, h, t, sc=sc) for t in range(int(z["n_frames"]))]
+    sha = np.frombuffer(__import__("hashlib").sha256(frames[0].tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha, z["frame0_sha"]), "synth.parallax_frame changed: regenerate tests/golden/track"
+    return frames
+
+
+@pytest.mark.parametrize("path", TRACK_GOLDEN)
+def test_cpu_pipeline_reproduces_the_pose_golden(path, oracle):
+    """The committed pose sequences pin the all-CPU pipeline (C oracle + vo_oracle) against drift."""
+    import track_ref
+    z = np.load(path)
+    outs = track_ref.run(oracle, _golden_frames(z), vo.Camera(*z["camera"]), int(z["n_features"]))
+    assert [o["state"] for o in outs] == list(z["state"])
+    assert np.array_equal(np.array([[o["n_keypoints"], o["n_matches"], o["n_inliers"], o["n_map_points"]] for o in outs]), z["counts"])
+    assert np.allclose(np.array([o["position"] for o in outs]), z["position"], rtol=0, atol=1e-9)
+    assert np.allclose(np.array([o["quaternion"] for o in outs]), z["quaternion"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", TRACK_GOLDEN)
+def test_ss_track_reproduces_the_pose_golden(path):
+    """ss_track through the C ABI against the committed pose sequences (no oracle at run time)."""
+    from send_slam_amd import binding
+    z = np.load(path)
+    fx, fy, cx, cy, k1, k2, p1, p2 = [float(v) for v in z["camera"]]
+    cam = binding.Camera(type=b"PinHole", fx=fx, fy=fy, cx=cx, cy=cy, k1=k1, k2=k2, p1=p1, p2=p2, width=int(z["width"]),
+                         height=int(z["height"]), fps=30, rgb=1, th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+    with binding.OrbContext(0, n_features=int(z["n_features"])) as ctx:
+        ctx.set_calibration(1, cam)
+        got = [ctx.track(f) for f in _golden_frames(z)]
+    assert [g["state"] for g in got] == list(z["state"])
+    assert np.array_equal(np.array([[g["n_keypoints"], g["n_matches"], g["n_inliers"], g["n_map_points"]] for g in got]), z["counts"])
+    assert np.allclose(np.array([g["position"] for g in got]), z["position"], rtol=0, atol=1e-6)
+    assert np.allclose(np.array([g["quaternion"] for g in got]), z["quaternion"], rtol=0, atol=1e-6)
