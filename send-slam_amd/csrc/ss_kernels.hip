@@ -4,14 +4,14 @@
  * Stage map; the reference's implementation of every stage is the
  * unvendored ORB-SLAM3 library entered at
  * /root/reference/slam_backends/orb_slam_3/orbslam3_mono_networked.cc:594:
- *   K0  k_ingest        cvtColor RGB/BGR -> gray (or pitched copy) into pyramid level 0
- *   K1  k_resize        ORBextractor::ComputePyramid: cv::resize INTER_LINEAR, level by level
- *   K2 + K6a k_fast_score  cv::FAST-9-16 corner response R-1 for every pixel (threshold-free) and,
- *                       from the same staged tile, GaussianBlur 7x7 sigma 2 (8-bit fixed-point path)
- *   K3  k_nms, k_cells_emit   35-px cell grid: NMS inside each cell window (sparse, on the corner
- *                       list FAST leaves; atomics for per-cell counts), iniTh -> minTh fallback, ordered
- *                       compaction into the candidate list (one wave per cell)
- *   K4  k_quadtree      ORBextractor::DistributeOctTree, one wave per (frame, level)
+ *   K0  k_ingest / k_ingest_gray16   cvtColor RGB/BGR -> gray (or pitched copy) into pyramid level 0
+ *   K1  k_resize_lds / k_resize      ORBextractor::ComputePyramid: cv::resize INTER_LINEAR, level by level
+ *   K2 + K3a + K6a  k_fast_score     cv::FAST-9-16 corner response R-1 (threshold-free), the NMS cv::FAST runs
+ *                       inside each 35-px cell window, and GaussianBlur 7x7 sigma 2 (8-bit fixed-point
+ *                       path) -- one staged tile feeds all three; survivors go to per-tile sub-lists
+ *   K3b k_bucket_gather, k_cells_emit  survivors regrouped per cell, iniTh -> minTh fallback, ordered
+ *                       compaction into the candidate list (rank of every survivor inside its cell)
+ *   K4  k_quadtree      ORBextractor::DistributeOctTree, one 4-wave workgroup per (frame, level)
  *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
  *   K7  k_match / k_match_merge   Hamming best / second best + ratio test
