@@ -967,18 +967,25 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
     if (lane == 0) qt_node(q, idx)->flags = d.flags & ~1; /* lNodes.erase */
 }
 
+#ifndef QT_WAVES
 #define QT_WAVES 4
+#endif
+#define QT_THREADS (QT_WAVES * 64)
 
-__global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
+template <int ITEMS_CAP>
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
                                                   uint32_t *__restrict__ qbuf0, uint32_t *__restrict__ qbuf1,
                                                   ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
                                                   uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
 {
-    __shared__ uint64_t items[QT_MAX_ITEMS];
+    __shared__ uint64_t items[ITEMS_CAP]; /* sized to the largest per-level list of the geometry: LDS a tree holds is LDS the other
+                                           * batches' FAST blocks cannot use while it is resident */
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
     __shared__ int grp_cnt[QT_WAVES][4];
     __shared__ int wave_alive[QT_WAVES];
-    const int level = blockIdx.x, frame = blockIdx.y;
+    /* frame fastest: the eight XCDs take workgroups round-robin, and with the level fastest every level-0 tree
+     * (the long ones) of a batch landed on one XCD, the other kernels in flight waiting for that XCD's share */
+    const int frame = blockIdx.x, level = blockIdx.y;
     const ss_level &L = g->lv[level];
     ss_level_state *st = state + (size_t)frame * SS_MAX_LEVELS_ + level;
     const int lane = lane_id();
@@ -1145,9 +1152,9 @@ __global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g,
             while (!finish && q.error == 0) {
                 const int prev2 = q.size;
                 const int n_prev = n_cur;
-                if (n_prev > QT_MAX_ITEMS) { q.error = -5; break; }
+                if (n_prev > ITEMS_CAP) { q.error = -5; break; }
                 /* vPrevSizeAndPointerToNode, in creation order; key = size, then UL.x */
-                for (int j = threadIdx.x; j < n_prev; j += 256) {
+                for (int j = threadIdx.x; j < n_prev; j += QT_THREADS) {
                     const int idx = cur[j];
                     const ss_qnode nd = *qt_node(q, idx);
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
@@ -1171,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const ss_geom *__restrict__ g,
     uint32_t *out = sel + (size_t)frame * g->sel_total + L.sel_base;
     int n_out = 0;
     if (q.error == 0) {
-        for (int hi = q.n_nodes - 1; hi >= 0; hi -= 256) {
+        for (int hi = q.n_nodes - 1; hi >= 0; hi -= QT_THREADS) {
             const int idx = hi - (int)threadIdx.x;
             ss_qnode nd;
             nd.flags = 0;
@@ -1677,8 +1684,15 @@ void ssk_cells_emit(hipStream_t s, const uint32_t *bucket, const ss_geom *dg, co
 void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cand, uint32_t *qbuf0,
                   uint32_t *qbuf1, ss_qnode *nodes, int32_t *lists, uint32_t *sel, ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_quadtree, dim3(hg.n_levels, n_frames), dim3(256), 0, s, dg, cand, qbuf0, qbuf1, nodes, lists,
-                       sel, state);
+    int need = 0;
+    for (int l = 0; l < hg.n_levels; l++) need = hg.lv[l].item_cap > need ? hg.lv[l].item_cap : need;
+    const dim3 grid(n_frames, hg.n_levels), block(QT_THREADS);
+    if (need <= 512)
+        hipLaunchKernelGGL(k_quadtree<512>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
+    else if (need <= 1024)
+        hipLaunchKernelGGL(k_quadtree<1024>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
+    else
+        hipLaunchKernelGGL(k_quadtree<QT_MAX_ITEMS>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
 }
 
 void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_level_state *state, uint32_t *kp_ref,
