@@ -772,19 +772,21 @@ __device__ void wave_insertion_sort(uint64_t *a, int first, int last, int lane)
 }
 
 /* std::sort(a, a + n, compareNodes) by the 64 lanes of one wave */
-__device__ void std_sort_items_wave(uint64_t *a, int n, int lane)
+/* `stack`: 64 words of LDS for the pending right-hand ranges (first | last << 12 | depth << 24): a local array
+ * here would be indexed dynamically and live in scratch memory, and a kernel that uses scratch costs the
+ * other kernels in flight far more than its instruction count */
+__device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane, uint32_t *stack)
 {
     if (n <= 0) return;
     int lg = 0;
     for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
-    int stack_first[64], stack_last[64], stack_depth[64];
     int sp = 1;
-    stack_first[0] = 0;
-    stack_last[0] = n;
-    stack_depth[0] = lg * 2;
+    if (lane == 0) stack[0] = 0u | ((uint32_t)n << 12) | ((uint32_t)(lg * 2) << 24);
+    wave_sync();
     while (sp > 0) {
         --sp;
-        int first = stack_first[sp], last = stack_last[sp], depth = stack_depth[sp];
+        const uint32_t top = stack[sp];
+        int first = (int)(top & 0xFFFu), last = (int)((top >> 12) & 0xFFFu), depth = (int)(top >> 24);
         while (last - first > 16) {
             if (depth == 0) {
                 wave_sync();
@@ -838,9 +840,8 @@ __device__ void std_sort_items_wave(uint64_t *a, int n, int lane)
                 ++lo;
             }
             if (sp < 64) {
-                stack_first[sp] = lo;
-                stack_last[sp] = last;
-                stack_depth[sp] = depth;
+                if (lane == 0) stack[sp] = (uint32_t)lo | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
+                wave_sync();
                 ++sp;
             }
             last = lo;
@@ -972,17 +973,18 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
 #endif
 #define QT_THREADS (QT_WAVES * 64)
 
-template <int ITEMS_CAP>
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restrict__ g, const uint32_t *__restrict__ cand,
                                                   uint32_t *__restrict__ qbuf0, uint32_t *__restrict__ qbuf1,
                                                   ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
-                                                  uint32_t *__restrict__ sel, ss_level_state *__restrict__ state)
+                                                  uint32_t *__restrict__ sel, ss_level_state *__restrict__ state, int items_cap)
 {
-    __shared__ uint64_t items[ITEMS_CAP]; /* sized to the largest per-level list of the geometry: LDS a tree holds is LDS the other
-                                           * batches' FAST blocks cannot use while it is resident */
+    /* dynamic LDS, sized by the launch to the largest per-level list of the geometry (items_cap entries): LDS a tree
+     * holds is LDS the other batches' FAST blocks cannot use while it is resident */
+    extern __shared__ uint64_t items[];
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
     __shared__ int grp_cnt[QT_WAVES][4];
     __shared__ int wave_alive[QT_WAVES];
+    __shared__ uint32_t sort_stack[64];
     /* frame fastest: the eight XCDs take workgroups round-robin, and with the level fastest every level-0 tree
      * (the long ones) of a batch landed on one XCD, the other kernels in flight waiting for that XCD's share */
     const int frame = blockIdx.x, level = blockIdx.y;
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             while (!finish && q.error == 0) {
                 const int prev2 = q.size;
                 const int n_prev = n_cur;
-                if (n_prev > ITEMS_CAP) { q.error = -5; break; }
+                if (n_prev > items_cap) { q.error = -5; break; }
                 /* vPrevSizeAndPointerToNode, in creation order; key = size, then UL.x */
                 for (int j = threadIdx.x; j < n_prev; j += QT_THREADS) {
                     const int idx = cur[j];
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
                 }
                 __syncthreads();
-                if (wave == 0) std_sort_items_wave(items, n_prev, lane);
+                if (wave == 0) std_sort_items_wave(items, n_prev, lane, sort_stack);
                 __syncthreads();
                 n_nxt = 0;
                 int dummy = 0;
@@ -1220,7 +1222,8 @@ __global__ __launch_bounds__(64) void k_debug_sort(uint64_t *__restrict__ data, 
     const int lane = lane_id();
     for (int i = lane; i < n; i += WAVE) items[i] = data[i];
     wave_sync();
-    std_sort_items_wave(items, n, lane);
+    __shared__ uint32_t sort_stack[64];
+    std_sort_items_wave(items, n, lane, sort_stack);
     wave_sync();
     for (int i = lane; i < n; i += WAVE) data[i] = items[i];
 }
@@ -1686,13 +1689,9 @@ void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uin
 {
     int need = 0;
     for (int l = 0; l < hg.n_levels; l++) need = hg.lv[l].item_cap > need ? hg.lv[l].item_cap : need;
-    const dim3 grid(n_frames, hg.n_levels), block(QT_THREADS);
-    if (need <= 512)
-        hipLaunchKernelGGL(k_quadtree<512>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
-    else if (need <= 1024)
-        hipLaunchKernelGGL(k_quadtree<1024>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
-    else
-        hipLaunchKernelGGL(k_quadtree<QT_MAX_ITEMS>, grid, block, 0, s, dg, cand, qbuf0, qbuf1, nodes, lists, sel, state);
+    need = (need + 63) & ~63;
+    hipLaunchKernelGGL(k_quadtree, dim3(n_frames, hg.n_levels), dim3(QT_THREADS), (size_t)need * sizeof(uint64_t), s, dg, cand, qbuf0,
+                       qbuf1, nodes, lists, sel, state, need);
 }
 
 void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_level_state *state, uint32_t *kp_ref,
