@@ -772,9 +772,8 @@ __device__ void wave_insertion_sort(uint64_t *a, int first, int last, int lane)
 }
 
 /* std::sort(a, a + n, compareNodes) by the 64 lanes of one wave */
-/* `stack`: 64 words of LDS for the pending right-hand ranges (first | last << 12 | depth << 24): a local array
- * here would be indexed dynamically and live in scratch memory, and a kernel that uses scratch costs the
- * other kernels in flight far more than its instruction count */
+/* `stack`: 64 words of LDS for the pending right-hand ranges (first | last << 12 | depth << 24); a local array
+ * would be indexed dynamically and live in scratch memory */
 __device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane, uint32_t *stack)
 {
     if (n <= 0) return;
