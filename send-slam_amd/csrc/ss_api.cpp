@@ -55,7 +55,7 @@ struct ss_ctx {
     ss_host_tables tabs;
     ss_geom *dg = nullptr;
     ss_rtab *d_rtab = nullptr;
-    uint32_t *d_tiles = nullptr, *d_tiles2 = nullptr;
+    uint32_t *d_tiles2 = nullptr;
 
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr;
     uint32_t *cell_cnt = nullptr;
@@ -178,7 +178,6 @@ void free_geometry_buffers(ss_ctx *c)
 {
     dev_free(c->dg);
     dev_free(c->d_rtab);
-    dev_free(c->d_tiles);
     dev_free(c->d_tiles2);
     dev_free(c->pyr);
     dev_free(c->blur);
@@ -225,8 +224,6 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->d_rtab, std::max<size_t>(c->tabs.rtab.size(), 1) * sizeof(ss_rtab)));
     if (!c->tabs.rtab.empty())
         HIP_TRY(c, hipMemcpy(c->d_rtab, c->tabs.rtab.data(), c->tabs.rtab.size() * sizeof(ss_rtab), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMalloc((void **)&c->d_tiles, c->tabs.tiles.size() * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(c->d_tiles, c->tabs.tiles.data(), c->tabs.tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->d_tiles2, c->tabs.tiles2.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_tiles2, c->tabs.tiles2.data(), c->tabs.tiles2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));

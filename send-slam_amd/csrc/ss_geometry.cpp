@@ -126,14 +126,13 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     }
 
     tabs->rtab.clear();
-    tabs->tiles.clear();
     tabs->tiles2.clear();
     tabs->cinfo.clear();
     tabs->tilecell.clear();
     tabs->cell_units.clear();
     uint32_t off = 0;
     int bucket_base = 0, chunk_base = 0;
-    int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile_base = 0, tile2_base = 0;
+    int cell_base = 0, cand_base = 0, sel_base = 0, node_base = 0, item_base = 0, tile2_base = 0;
     for (int l = 0; l < p.n_levels; l++) {
         ss_level &L = g->lv[l];
         L.w = cv_round((float)width * inv_scale[l]);
@@ -214,13 +213,7 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
         L.item_cap = align_up(most + 16, 8);
         item_base += L.item_cap;
 
-        L.tile_base = tile_base;
         L.tiles_x = (L.w + SS_TILE_W - 1) / SS_TILE_W;
-        L.tiles_y = (L.h + SS_TILE_H - 1) / SS_TILE_H;
-        tile_base += L.tiles_x * L.tiles_y;
-        for (int ty = 0; ty < L.tiles_y; ty++)
-            for (int tx = 0; tx < L.tiles_x; tx++)
-                tabs->tiles.push_back(((uint32_t)l << 20) | ((uint32_t)ty << 8) | (uint32_t)tx);
 
         L.tile2_base = tile2_base;
         L.tiles2_y = (L.h + SS_TILE_H2 - 1) / SS_TILE_H2;
@@ -293,7 +286,6 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     g->sel_total = sel_base;
     g->node_total = node_base;
     g->item_total = item_base;
-    g->tiles_total = tile_base;
     g->tiles2_total = tile2_base;
     g->kcap = align_up(sel_base, 64);
     return SS_OK;

@@ -29,7 +29,6 @@
 
 #define SS_MAX_LEVELS_ 16
 #define SS_TILE_W 64
-#define SS_TILE_H 16
 #define SS_TILE_H2 32 /* tall tiles for the FAST and blur kernels */
 /* NMS survivors of one 64x32 tile: a tile meets at most 3 x 2 cell windows (cells are >= 35 px) and
  * survivors of ONE window are never 8-adjacent, so <= (32 + 1) * (16 + 1) of them */
@@ -56,9 +55,9 @@ typedef struct {
     int32_t sel_base, sel_cap;
     int32_t node_base, node_cap; /* quadtree nodes */
     int32_t item_base, item_cap; /* quadtree sort items / expandable lists */
-    /* 64x16 tiles for the image kernels */
-    int32_t tile_base, tiles_x, tiles_y;
-    int32_t tile2_base, tiles2_y; /* 64x32 tiles */
+    /* 64x32 tiles of the FAST / blur kernel */
+    int32_t tiles_x;
+    int32_t tile2_base, tiles2_y;
     /* resize tables for building THIS level from level-1 (entries of 8 bytes) */
     int32_t xtab_off, ytab_off;
     /* cell-window tables (u16 per column / row of the level): SS_CI_* bits | cell index */
@@ -85,7 +84,6 @@ typedef struct {
     int32_t sel_total;
     int32_t node_total;
     int32_t item_total;
-    int32_t tiles_total;
     int32_t tiles2_total;
     int32_t umax[16];
     ss_level lv[SS_MAX_LEVELS_];
