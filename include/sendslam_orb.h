@@ -205,7 +205,9 @@ int ss_profile_reset(ss_ctx *ctx);
 int ss_stats(ss_ctx *ctx, ss_stage_stats *out, int max_stages);
 
 /* Intermediate buffers of the last batch, for stage-by-stage parity tests.  what:
- * 0 pyramid level, 1 blurred level, 2 FAST score map (tight w*h u8 each); 3 candidates,
+ * 0 pyramid level, 1 blurred level, 2 FAST score map (tight w*h u8 each; no kernel reads the map, so it
+ * is not kept in normal operation: the first request allocates it, re-runs the FAST kernel on the last
+ * batch's pyramid, and the context keeps it from then on); 3 candidates,
  * 4 quadtree-selected keypoints of a level (int32 triples x, y, response; candidates are
  * relative to the (16,16) border origin, selected are level coordinates).  Returns the
  * number of bytes written to dst (<= dst_bytes) or < 0. */
