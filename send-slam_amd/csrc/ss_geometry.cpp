@@ -260,7 +260,7 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
                             const int tile = L.tile2_base + ty * L.tiles_x + tx;
                             const uint32_t tc = tabs->tilecell[tile];
                             const int kc = cj - (int)(tc & 0xFFFFu), kr = ci - (int)(tc >> 16);
-                            if (kc < 0 || kc >= 3 || kr < 0 || kr >= 2 || n_units >= SS_CELL_UNITS) {
+                            if (kc < 0 || kc >= 3 || kr < 0 || kr >= SS_TS_ROWS || n_units >= SS_CELL_UNITS) {
                                 *err = "unsupported cell / tile geometry at level " + std::to_string(l);
                                 return SS_ERR_INVALID_ARG;
                             }

@@ -237,7 +237,8 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr,
+#define FT_THREADS (8 * SS_TILE_H2)
+__global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__restrict__ pyr,
                                                     uint8_t *__restrict__ score,
                                                     const ss_geom *__restrict__ g,
                                                     const uint32_t *__restrict__ tiles,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += 256) (&out_tile[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += FT_THREADS) (&out_tile[0][0])[i] = 0;
     if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = x0 + (int)threadIdx.x < w ? cinfo[L.xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
     else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) {
         const int k = (int)threadIdx.x - SS_TILE_W;
@@ -290,16 +291,16 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         const uint32_t off = (uint32_t)(ty * pitch + 4 * tx);
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
-            const int r = ty + 16 * rr;
+            const int r = ty + (FT_THREADS / 16) * rr;
             if (r < FT_ROWS) {
-                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)(16 * rr * pitch));
-                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)(16 * rr * pitch) + 64);
+                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * pitch));
+                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * pitch) + 64);
             }
         }
     } else {
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
-            const int r = ty + 16 * rr;
+            const int r = ty + (FT_THREADS / 16) * rr;
             if (r < FT_ROWS) {
                 const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * pitch;
                 if (inner_x) {
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
         constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
         uint16_t *h16 = (uint16_t *)&hpair[0][0];
-        for (int idx = threadIdx.x; idx < FT_BLUR_ROWS * 16; idx += 256) {
+        for (int idx = threadIdx.x; idx < FT_BLUR_ROWS * 16; idx += FT_THREADS) {
             const int r = idx >> 4, q = idx & 15; /* blur row r = staged row r + 1 */
             const uint32_t w0 = lds[r + 1][q], w1 = lds[r + 1][q + 1], w2 = lds[r + 1][q + 2];
             uint32_t hv[4];
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     uint8_t *out8 = (uint8_t *)&out_tile[0][0];
     const int n = n_list;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    for (int e = threadIdx.x; e < n; e += FT_THREADS) {
         const int ly = (int)(list[e] >> 8) - 1, lx = (int)(list[e] & 0xFF) - 1;
         const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
         const int v = c[0];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     const int nc = n_corner, ini_th = g->ini_th;
     const uint32_t tc = tilecell[tile];
     const int col0 = (int)(tc & 0xFFFFu), row0 = (int)(tc >> 16);
-    for (int e = threadIdx.x; e < nc; e += 256) {
+    for (int e = threadIdx.x; e < nc; e += FT_THREADS) {
         const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
         const uint32_t xi = xinf[lx], yi = yinf[ly];
         uint16_t code = 0xFFFFu;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
     __syncthreads();
     const size_t tslot = (size_t)frame * g->tiles2_total + tile;
     if (threadIdx.x < SS_TS_HDR) thdr[tslot * SS_TS_HDR + threadIdx.x] = s_kcnt[threadIdx.x];
-    for (int e = threadIdx.x; e < nc; e += 256) {
+    for (int e = threadIdx.x; e < nc; e += FT_THREADS) {
         const uint32_t code = list[e];
         if (code == 0xFFFFu) continue;
         const int k = (int)(code >> 12);
@@ -1669,7 +1670,7 @@ void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_
                        const uint32_t *tiles, const uint16_t *cinfo, const uint32_t *tilecell, uint32_t *tsurv, uint32_t *thdr,
                        ss_level_state *state, int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(256), 0, s, pyr, score, dg, tiles, cinfo, tilecell, tsurv,
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(FT_THREADS), 0, s, pyr, score, dg, tiles, cinfo, tilecell, tsurv,
                        thdr, state, blur);
 }
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,

@@ -29,12 +29,15 @@
 
 #define SS_MAX_LEVELS_ 16
 #define SS_TILE_W 64
-#define SS_TILE_H2 32 /* tall tiles for the FAST and blur kernels */
+#ifndef SS_TILE_H2
+#define SS_TILE_H2 32 /* tile height of the FAST / NMS / blur kernel (32 or 64; 8 * SS_TILE_H2 threads per block) */
+#endif
 /* NMS survivors of one 64x32 tile: a tile meets at most 3 x 2 cell windows (cells are >= 35 px) and
  * survivors of ONE window are never 8-adjacent, so <= (32 + 1) * (16 + 1) of them */
-#define SS_TS_CAP 576
-#define SS_TS_CELLS 6   /* sub-lists per tile: (cell row - first row) * 3 + (cell col - first col) */
-#define SS_TS_HDR 8     /* header words per tile (SS_TS_CELLS count words, padded) */
+#define SS_TS_ROWS (SS_TILE_H2 > 32 ? 3 : 2) /* cell rows a tile can meet (cells are >= 35 px) */
+#define SS_TS_CAP (SS_TILE_H2 > 32 ? 1152 : 576)
+#define SS_TS_CELLS (3 * SS_TS_ROWS) /* sub-lists per tile: (cell row - first row) * 3 + (cell col - first col) */
+#define SS_TS_HDR (SS_TILE_H2 > 32 ? 12 : 8) /* header words per tile (SS_TS_CELLS count words, padded) */
 #define SS_CELL_UNITS 12 /* (tile, sub-list) pairs one cell can be spread over */
 
 #define SS_PACK(x, y, r) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
