@@ -1442,21 +1442,37 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     const int t0 = imin(c0 + wave * quarter, c1), t1 = imin(t0 + quarter, c1);
 
     uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-    /* 16 VALU per pair for the distance (XOR + popcount-accumulate with SGPR operands) + 6 to
-     * form the key, mask the self pair and keep the two smallest keys.  Unrolled by 4 so several
-     * s_load_dwordx8 are in flight before the first XOR needs its operand. */
-    const uint32_t skip = excl ? (uint32_t)(qi - t0) : 0xFFFFFFFFu; /* local index this lane must skip */
+    /* 16 VALU per pair for the distance (XOR + popcount-accumulate with SGPR operands) + 3 to form the key and
+     * keep the two smallest keys (k1 <= k2 always, so the new second is the median of k1, k2 and the key: one
+     * v_med3_u32) + 2 to mask the self pair -- which only the waves whose train rows overlap the block's own
+     * 64 query rows have to do (wave-uniform test).  Unrolled by 4 so several s_load_dwordx8 are in flight
+     * before the first XOR needs its operand. */
+    const bool self_in_range = excl && t0 < (int)(blockIdx.x * 64 + 64) && t1 > (int)(blockIdx.x * 64);
+    if (self_in_range) {
+        const uint32_t skip = (uint32_t)(qi - t0); /* local index this lane must skip */
 #pragma unroll 4
-    for (int j = t0; j < t1; j++) {
-        const uint32_t *tj = tf + (size_t)j * 8;
-        uint32_t d = 0;
+        for (int j = t0; j < t1; j++) {
+            const uint32_t *tj = tf + (size_t)j * 8;
+            uint32_t d = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
-        const uint32_t jl = (uint32_t)(j - t0);
-        uint32_t key = (d << 16) | jl;
-        key = jl == skip ? 0xFFFFFFFFu : key;
-        k2 = min(k2, max(k1, key));
-        k1 = min(k1, key);
+            for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
+            const uint32_t jl = (uint32_t)(j - t0);
+            uint32_t key = (d << 16) | jl;
+            key = jl == skip ? 0xFFFFFFFFu : key;
+            k2 = min(max(k1, k2), max(min(k1, k2), key));
+            k1 = min(k1, key);
+        }
+    } else {
+#pragma unroll 4
+        for (int j = t0; j < t1; j++) {
+            const uint32_t *tj = tf + (size_t)j * 8;
+            uint32_t d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) d += __popc(qw[k] ^ tj[k]);
+            const uint32_t key = (d << 16) | (uint32_t)(j - t0);
+            k2 = min(max(k1, k2), max(min(k1, k2), key));
+            k1 = min(k1, key);
+        }
     }
     int d1 = (int)(k1 >> 16), d2 = (int)(k2 >> 16);
     int j1 = d1 == 0xFFFF ? -1 : t0 + (int)(k1 & 0xFFFF);
