@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
 /* K7: Hamming best / second best.  Lane = one query descriptor (8 dwords in VGPRs); the   */
 /* train descriptor of an iteration is wave-uniform, so its 8 dwords arrive by scalar      */
 /* loads and feed v_xor / v_bcnt (popcount-accumulate) as SGPR operands: 16 VALU per pair  */
-/* + 4 to keep the two smallest keys.  key = distance << 16 | local train index: the       */
+/* + 3 to keep the two smallest keys.  key = distance << 16 | local train index: the       */
 /* minimum key is the best distance with the LOWEST index, the second-smallest key carries */
 /* the second-best distance (DESIGN.md "match").  A block = 64 queries x one train chunk,   */
 /* its 4 waves take quarter-chunks and merge through LDS.                                  */
