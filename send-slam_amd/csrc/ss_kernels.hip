@@ -473,16 +473,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
         constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
         constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
-        uint32_t out_a = 0, out_b = 0;
+        uint32_t va[4], vb[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
             const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
-            const uint32_t a = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
-            const uint32_t b = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
-            out_a |= ((a >> 16) & 0xFFu) << (8 * i);
-            out_b |= ((b >> 16) & 0xFFu) << (8 * i);
+            va[i] = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
+            vb[i] = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
         }
+        /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24): three v_perm_b32 gather four of them */
+        const uint32_t out_a = __builtin_amdgcn_perm(va[1], va[0], 0x0C0C0602u) | __builtin_amdgcn_perm(va[3], va[2], 0x06020C0Cu);
+        const uint32_t out_b = __builtin_amdgcn_perm(vb[1], vb[0], 0x0C0C0602u) | __builtin_amdgcn_perm(vb[3], vb[2], 0x06020C0Cu);
         const int ya = y0 + 2 * ty;
         if (x0 + 4 * tx < pitch) {
             if (ya < h) *(uint32_t *)(blur + fb + (size_t)ya * pitch + x0 + 4 * tx) = out_a;
