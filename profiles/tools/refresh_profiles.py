@@ -18,11 +18,15 @@ STAGE = {"k_ingest_gray16": "ingest", "k_ingest": "ingest", "k_resize_lds": "res
          "k_orient_describe": "orient_describe", "k_match": "match"}
 
 
+def newest(d, pattern):
+    """gpurun merges new files into gpurun_out/ without removing old ones: take the latest run only"""
+    f = glob.glob(os.path.join(out_dir, d, "**", pattern), recursive=True)
+    return max(f, key=os.path.getmtime) if f else None
+
+
 def rows(d):
-    r = []
-    for f in glob.glob(os.path.join(out_dir, d, "**", "*counter_collection.csv"), recursive=True):
-        r += list(csv.DictReader(open(f)))
-    return r
+    f = newest(d, "*counter_collection.csv")
+    return list(csv.DictReader(open(f))) if f else []
 
 
 def per_kernel(d):
@@ -57,9 +61,9 @@ json.dump(raw, open(os.path.join(here, "r01_pmc_fetch_write_per_launch.json"), "
 sq = {n: dict({c: round(v) for c, v in d.items()}, launches_summed=k) for n, (d, k) in per_kernel("pmc_sq").items()}
 json.dump(sq, open(os.path.join(here, "r01_pmc_sq_mix.json"), "w"), indent=1)
 for src, dst in (("prof4", "r01_bench_kernel_stats.csv"), ("prof1", "r01_bench_kernel_stats_1ctx.csv")):
-    f = glob.glob(os.path.join(out_dir, src, "**", "*kernel_stats.csv"), recursive=True)
+    f = newest(src, "*kernel_stats.csv")
     if f:
-        shutil.copy(f[0], os.path.join(here, dst))
+        shutil.copy(f, os.path.join(here, dst))
 if os.path.exists(os.path.join(out_dir, "bench_final.json")):
     shutil.copy(os.path.join(out_dir, "bench_final.json"), os.path.join(here, "r01_bench.json"))
 tot = sum(v.get("SQ_INSTS_VALU", 0) for v in sq.values())
