@@ -165,10 +165,22 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     const int gy0 = (int)rtab[D.ytab_off + imin(y0, D.h - 1)].s0;
     const int gy1 = (int)rtab[D.ytab_off + imin(y0 + RS_TILE_H - 1, D.h - 1)].s1; /* last source row used */
 
-    for (int idx = threadIdx.x; idx < RS_ROWS * RS_WORDS; idx += 256) {
-        const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
-        const int gy = gy0 + r, gx = gx0 + 4 * c;
-        if (gy <= gy1 && gx < S.pitch) lds[r][c] = *(const uint32_t *)(src + (size_t)gy * S.pitch + gx);
+    {
+        /* all of a thread's loads first, then the LDS stores: one memory latency instead of one per round */
+        constexpr int ROUNDS = (RS_ROWS * RS_WORDS + 255) / 256;
+        uint32_t v[ROUNDS];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
+            const int gy = gy0 + r, gx = gx0 + 4 * c;
+            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < S.pitch) ? *(const uint32_t *)(src + (size_t)gy * S.pitch + gx) : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            if (idx < RS_ROWS * RS_WORDS) (&lds[0][0])[idx] = v[it];
+        }
     }
     __syncthreads();
 
@@ -642,9 +654,13 @@ __global__ __launch_bounds__(256) void k_cells_emit(const uint32_t *__restrict__
         if (use_ini && (int)(rec >> 24) < ini_th) continue;
         const uint32_t key = rec & 0xFFFFFFu; /* y in bits 12..23 above x: row-major order */
         int rank = 0;
-        for (int j = 0; j < n_all; j++) {
-            const uint32_t o = bk[j];
-            rank += ((!use_ini || (int)(o >> 24) >= ini_th) && (o & 0xFFFFFFu) < key) ? 1 : 0;
+        for (int j0 = 0; j0 < n_all; j0 += 4) { /* four entries per round: their loads are in flight together */
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = bk[imin(j0 + q, n_all - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                rank += (j0 + q < n_all && (!use_ini || (int)(o[q] >> 24) >= ini_th) && (o[q] & 0xFFFFFFu) < key) ? 1 : 0;
         }
         out[s_out[c] + rank] = rec;
     }
@@ -1317,9 +1333,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
     {
         const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
-        for (int idx = lane; idx < 31 * 10; idx += WAVE) {
-            const int r = idx / 10, c = idx - r * 10;
-            patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
+#pragma unroll
+        for (int it = 0; it < 5; it++) { /* 310 dwords = 4 full rounds of the wave + 54 lanes */
+            const int idx = lane + WAVE * it;
+            if (idx < 31 * 10) {
+                const int r = idx / 10, c = idx - r * 10;
+                patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
+            }
         }
     }
     wave_sync();
@@ -1332,8 +1352,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             const uint8_t *p = (const uint8_t *)&patch[row][0] + (kx - px0);
             const int u0 = half ? 0 : -d, u1 = half ? d : -1;
             int rs = 0;
-            for (int u = u0; u <= u1; u++) {
-                const int val = p[u];
+            /* fixed 16 steps with the tail masked: the 16 LDS byte reads issue back to back and their latency is
+             * paid once, instead of once per step of a data-dependent loop (u0 + k stays inside the staged row) */
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int u = u0 + k;
+                const int val = u <= u1 ? (int)p[u] : 0;
                 m10 += u * val;
                 rs += val;
             }
