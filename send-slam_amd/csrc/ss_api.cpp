@@ -246,7 +246,7 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->lists, B * g.item_total * 2 * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->sel, B * g.sel_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->state, B * SS_MAX_LEVELS * sizeof(ss_level_state)));
-    HIP_TRY(c, hipMalloc((void **)&c->kp_ref, B * g.kcap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->kp_ref, B * g.kcap * 2 * sizeof(uint32_t))); /* (reference, record) per output slot */
     HIP_TRY(c, hipMalloc((void **)&c->n_kp, B * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->level_counts, B * SS_MAX_LEVELS * sizeof(int32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->frame_error, B * sizeof(int32_t)));

@@ -395,7 +395,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
         constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
         uint16_t *h16 = (uint16_t *)&hpair[0][0];
-        for (int idx = threadIdx.x; idx < FT_BLUR_ROWS * 16; idx += FT_THREADS) {
+#pragma unroll
+        for (int it = 0; it < (FT_BLUR_ROWS * 16 + FT_THREADS - 1) / FT_THREADS; it++) {
+            const int idx = (int)threadIdx.x + FT_THREADS * it;
+            if (idx >= FT_BLUR_ROWS * 16) break;
             const int r = idx >> 4, q = idx & 15; /* blur row r = staged row r + 1 */
             const uint32_t w0 = lds[r + 1][q], w1 = lds[r + 1][q + 1], w2 = lds[r + 1][q + 2];
             uint32_t hv[4];
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
     }
     if (err) return;
     const float lap0 = (float)g->lap_x0, lap1 = (float)g->lap_x1;
-    uint32_t *ref = kp_ref + (size_t)frame * g->kcap;
+    uint2 *ref = (uint2 *)kp_ref + (size_t)frame * g->kcap; /* (level << 16 | index, the record itself) */
     int mono = 0, stereo = total - 1;
     for (int l = 0; l < g->n_levels; l++) {
         const ss_level &L = g->lv[l];
@@ -1289,7 +1292,7 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
             const uint64_t ms = __ballot(valid && is_st), mm = __ballot(valid && !is_st);
             if (valid) {
                 const int slot = is_st ? stereo - __popcll(ms & lt) : mono + __popcll(mm & lt);
-                ref[slot] = ((uint32_t)l << 16) | (uint32_t)i;
+                ref[slot] = make_uint2(((uint32_t)l << 16) | (uint32_t)i, s[i]);
             }
             stereo -= __popcll(ms);
             mono += __popcll(mm);
@@ -1318,10 +1321,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     const int slot = rfl((logical - frame * (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6));
     if (slot >= n_kp[frame]) return;
     const int lane = lane_id();
-    const uint32_t ref = kp_ref[(size_t)frame * g->kcap + slot];
-    const int level = (int)(ref >> 16), i = (int)(ref & 0xFFFF);
+    const uint2 ref = ((const uint2 *)kp_ref)[(size_t)frame * g->kcap + slot]; /* k_slots left the record next to its
+                                                                               * reference: one load, not two in a row */
+    const int level = (int)(ref.x >> 16);
     const ss_level &L = g->lv[level];
-    const uint32_t rec = sel[(size_t)frame * g->sel_total + L.sel_base + i];
+    const uint32_t rec = ref.y;
     const int kx = SS_PX(rec), ky = SS_PY(rec), resp = SS_PR(rec);
     const size_t fb = (size_t)frame * g->block_bytes + L.off;
     const int pitch = L.pitch;
@@ -1331,6 +1335,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     __shared__ uint32_t patch_all[4][31][10];
     uint32_t(*patch)[10] = patch_all[threadIdx.x >> 6];
     const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
+    uint32_t pat[4]; /* this lane's four sample pairs of the pattern: independent of the keypoint, requested first */
+#pragma unroll
+    for (int k = 0; k < 4; k++) pat[k] = *(const uint32_t *)(c_pattern + 4 * (lane + 64 * k));
     {
         const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
 #pragma unroll
@@ -1370,21 +1377,31 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     float b, a;
     ss_sincosf_deg(angle, &b, &a);
 
-    /* steered rBRIEF */
+    /* steered rBRIEF: the eight sample addresses of a lane first, then the eight byte loads together, then the
+     * four ballots (the pattern words were requested before the IC stage) */
     const uint8_t *center = blur + fb + (size_t)ky * pitch + kx;
-    uint64_t words[4];
+    int off0[4], off1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t pt = *(const uint32_t *)(c_pattern + 4 * (lane + 64 * k)); /* x0 y0 x1 y1 as int8 */
+        const uint32_t pt = pat[k]; /* x0 y0 x1 y1 as int8 */
         const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
         const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
-        words[k] = __ballot(t0 < t1);
+        off0[k] = r0 * pitch + c0;
+        off1[k] = r1 * pitch + c1;
     }
+    int t0[4], t1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        t0[k] = center[off0[k]];
+        t1[k] = center[off1[k]];
+    }
+    uint64_t words[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) words[k] = __ballot(t0[k] < t1[k]);
     if (lane == 0) {
         uint64_t *d = (uint64_t *)(desc + ((size_t)frame * g->kcap + slot) * SS_DESC_BYTES);
         d[0] = words[0];
