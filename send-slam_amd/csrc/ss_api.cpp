@@ -55,7 +55,7 @@ struct ss_ctx {
     ss_host_tables tabs;
     ss_geom *dg = nullptr;
     ss_rtab *d_rtab = nullptr;
-    uint32_t *d_tiles2 = nullptr;
+    uint32_t *d_tiles2 = nullptr; /* per-tile records of the FAST kernel (SS_TILE_REC_WORDS each) */
 
     uint8_t *pyr = nullptr, *blur = nullptr, *score = nullptr;
     uint32_t *cell_cnt = nullptr;
@@ -63,7 +63,7 @@ struct ss_ctx {
     uint32_t *cand = nullptr, *qbuf0 = nullptr, *qbuf1 = nullptr;
     uint32_t *bucket = nullptr; /* per cell: NMS survivors, unordered */
     uint32_t *tsurv = nullptr, *thdr = nullptr; /* per 64x32 tile: survivor sub-lists and their count words */
-    uint32_t *d_tilecell = nullptr, *d_cell_units = nullptr;
+    uint32_t *d_cell_units = nullptr;
     ss_qnode *nodes = nullptr;
     int32_t *lists = nullptr;
     uint32_t *sel = nullptr;
@@ -190,7 +190,6 @@ void free_geometry_buffers(ss_ctx *c)
     dev_free(c->bucket);
     dev_free(c->tsurv);
     dev_free(c->thdr);
-    dev_free(c->d_tilecell);
     dev_free(c->d_cell_units);
     dev_free(c->nodes);
     dev_free(c->lists);
@@ -224,8 +223,8 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->d_rtab, std::max<size_t>(c->tabs.rtab.size(), 1) * sizeof(ss_rtab)));
     if (!c->tabs.rtab.empty())
         HIP_TRY(c, hipMemcpy(c->d_rtab, c->tabs.rtab.data(), c->tabs.rtab.size() * sizeof(ss_rtab), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMalloc((void **)&c->d_tiles2, c->tabs.tiles2.size() * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(c->d_tiles2, c->tabs.tiles2.data(), c->tabs.tiles2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&c->d_tiles2, c->tabs.tile_recs.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_tiles2, c->tabs.tile_recs.data(), c->tabs.tile_recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->pyr, B * g.block_bytes));
     HIP_TRY(c, hipMalloc((void **)&c->blur, B * g.block_bytes));
     /* c->score (the FAST response map) is allocated by the first ss_debug_fetch(2): no kernel reads it */
@@ -238,8 +237,6 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMalloc((void **)&c->bucket, B * g.bucket_total * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->tsurv, B * g.tiles2_total * (size_t)SS_TS_CAP * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc((void **)&c->thdr, B * g.tiles2_total * (size_t)SS_TS_HDR * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_tilecell, c->tabs.tilecell.size() * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(c->d_tilecell, c->tabs.tilecell.data(), c->tabs.tilecell.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->d_cell_units, c->tabs.cell_units.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_cell_units, c->tabs.cell_units.data(), c->tabs.cell_units.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc((void **)&c->nodes, B * g.node_total * sizeof(ss_qnode)));
@@ -290,7 +287,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map and the
          * survivor lists are this design's own intermediates) */
         stage_timer t(c, "fast_blur_nms", n * 2 * all_px);
-        ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->d_tilecell, c->tsurv, c->thdr, c->state, n);
+        ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv, c->thdr, c->state, n);
     }
     {
         stage_timer t(c, "bucket_gather", 0);
@@ -752,7 +749,7 @@ int ss_debug_fetch(ss_ctx *c, int what, int frame, int level, void *dst, int64_t
              * again on the pyramid of the last batch (same kernel, same outputs, plus the map);
              * from now on this context keeps it */
             HIP_TRY(c, hipMalloc((void **)&c->score, (size_t)c->params.max_batch * g.block_bytes));
-            ssk_fast_blur_nms(c->stream, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->d_tilecell, c->tsurv,
+            ssk_fast_blur_nms(c->stream, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv,
                               c->thdr, c->state, c->last_n_frames);
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }

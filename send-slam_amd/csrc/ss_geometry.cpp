@@ -129,6 +129,7 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
     tabs->tiles2.clear();
     tabs->cinfo.clear();
     tabs->tilecell.clear();
+    tabs->tile_recs.clear();
     tabs->cell_units.clear();
     uint32_t off = 0;
     int bucket_base = 0, chunk_base = 0;
@@ -235,6 +236,11 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
                     const int col0 = first_cell(xin, tx * SS_TILE_W, std::min((tx + 1) * SS_TILE_W, L.w));
                     const int row0 = first_cell(yin, ty * SS_TILE_H2, std::min((ty + 1) * SS_TILE_H2, L.h));
                     tabs->tilecell.push_back((uint32_t)col0 | ((uint32_t)row0 << 16));
+                    const uint32_t rec[SS_TILE_REC_WORDS] = {(uint32_t)l, (uint32_t)(tx * SS_TILE_W), (uint32_t)(ty * SS_TILE_H2),
+                                                             (uint32_t)L.w, (uint32_t)L.h, (uint32_t)L.pitch, L.off,
+                                                             (uint32_t)L.xinfo_off, (uint32_t)L.yinfo_off,
+                                                             (uint32_t)col0 | ((uint32_t)row0 << 16)};
+                    tabs->tile_recs.insert(tabs->tile_recs.end(), rec, rec + SS_TILE_REC_WORDS);
                 }
             const size_t ubase = tabs->cell_units.size();
             tabs->cell_units.resize(ubase + (size_t)L.n_cols * L.n_rows * SS_CELL_UNITS, 0xFFFFFFFFu);

@@ -12,6 +12,7 @@ struct ss_host_tables {
     std::vector<ss_rtab> rtab;   /* resize coefficient tables, all levels */
     std::vector<uint32_t> tiles2; /* 64x32 tiles: level << 20 | tile_y << 8 | tile_x, all levels */
     std::vector<uint16_t> cinfo; /* cell-window info per column / row, all levels */
+    std::vector<uint32_t> tile_recs;  /* SS_TILE_REC_WORDS words per 64x32 tile, tiles2 order */
     std::vector<uint32_t> tilecell;   /* per 64x32 tile: first cell column | first cell row << 16 */
     std::vector<uint32_t> cell_units; /* per cell: SS_CELL_UNITS x (tile2 index | sub-list << 24), ~0 = end */
 };

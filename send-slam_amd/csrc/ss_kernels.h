@@ -15,8 +15,8 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
 /* K2 + K3a + K6a fused: FAST response map, in-window NMS into per-tile survivor sub-lists, blurred pyramid -- one
  * staged tile, no global atomics */
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-                       const uint32_t *tiles, const uint16_t *cinfo, const uint32_t *tilecell, uint32_t *tsurv, uint32_t *thdr,
-                       ss_level_state *state, int n_frames);
+                       const uint32_t *tile_recs, const uint16_t *cinfo, uint32_t *tsurv, uint32_t *thdr, ss_level_state *state,
+                       int n_frames);
 /* tile sub-lists -> per-cell buckets + count words (one thread per cell) */
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
                        const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames);

@@ -255,7 +255,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
                                                     const ss_geom *__restrict__ g,
                                                     const uint32_t *__restrict__ tiles,
                                                     const uint16_t *__restrict__ cinfo,
-                                                    const uint32_t *__restrict__ tilecell,
                                                     uint32_t *__restrict__ tsurv,
                                                     uint32_t *__restrict__ thdr,
                                                     ss_level_state *__restrict__ state,
@@ -274,22 +273,24 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     __shared__ uint32_t s_kcnt[SS_TS_HDR]; /* count words of the tile's sub-lists */
     __shared__ int n_list, n_corner;
     const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const uint32_t t = tiles[tile];
-    const int level = (int)(t >> 20), x0 = (int)(t & 0xFF) * SS_TILE_W, y0 = (int)((t >> 8) & 0x3FF) * SS_TILE_H2;
-    const ss_level &L = g->lv[level];
+    /* everything a block needs to know about its tile in ONE 64-byte record (ss_geometry.cpp): the staging loads
+     * wait for one scalar load instead of the chain tile word -> level -> level fields */
+    const uint32_t *tr = tiles + (size_t)tile * SS_TILE_REC_WORDS;
+    const int level = (int)tr[0], x0 = (int)tr[1], y0 = (int)tr[2];
+    const int w = (int)tr[3], h = (int)tr[4], pitch = (int)tr[5];
+    const int xinfo_off = (int)tr[7], yinfo_off = (int)tr[8];
     const int frame = blockIdx.y;
-    const size_t fb = (size_t)frame * g->block_bytes + L.off;
+    const size_t fb = (size_t)frame * g->block_bytes + tr[6];
     const uint8_t *img = pyr + fb;
-    const int w = L.w, h = L.h, pitch = L.pitch;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += FT_THREADS) (&out_tile[0][0])[i] = 0;
-    if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = x0 + (int)threadIdx.x < w ? cinfo[L.xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
+    if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = x0 + (int)threadIdx.x < w ? cinfo[xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
     else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) {
         const int k = (int)threadIdx.x - SS_TILE_W;
-        yinf[k] = y0 + k < h ? cinfo[L.yinfo_off + y0 + k] : (uint16_t)0;
+        yinf[k] = y0 + k < h ? cinfo[yinfo_off + y0 + k] : (uint16_t)0;
     }
     /* stage rows y0-4 .. y0+35, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
      * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * from an LDS counter, so no global atomic is involved: pass 1 here allots the slots, pass 2
      * (after the blur's vertical pass) knows the sub-list offsets and writes the records. */
     const int nc = n_corner, ini_th = g->ini_th;
-    const uint32_t tc = tilecell[tile];
+    const uint32_t tc = tr[9];
     const int col0 = (int)(tc & 0xFFFFu), row0 = (int)(tc >> 16);
     for (int e = threadIdx.x; e < nc; e += FT_THREADS) {
         const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
@@ -1725,11 +1726,11 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
 }
 
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
-                       const uint32_t *tiles, const uint16_t *cinfo, const uint32_t *tilecell, uint32_t *tsurv, uint32_t *thdr,
-                       ss_level_state *state, int n_frames)
+                       const uint32_t *tile_recs, const uint16_t *cinfo, uint32_t *tsurv, uint32_t *thdr, ss_level_state *state,
+                       int n_frames)
 {
-    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(FT_THREADS), 0, s, pyr, score, dg, tiles, cinfo, tilecell, tsurv,
-                       thdr, state, blur);
+    hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(FT_THREADS), 0, s, pyr, score, dg, tile_recs, cinfo, tsurv, thdr,
+                       state, blur);
 }
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
                        const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames)

@@ -38,6 +38,7 @@
 #define SS_TS_CAP (SS_TILE_H2 > 32 ? 1152 : 576)
 #define SS_TS_CELLS (3 * SS_TS_ROWS) /* sub-lists per tile: (cell row - first row) * 3 + (cell col - first col) */
 #define SS_TS_HDR (SS_TILE_H2 > 32 ? 12 : 8) /* header words per tile (SS_TS_CELLS count words, padded) */
+#define SS_TILE_REC_WORDS 16 /* per-tile record of the FAST kernel: level, x0, y0, w, h, pitch, off, xinfo_off, yinfo_off, first cells */
 #define SS_CELL_UNITS 12 /* (tile, sub-list) pairs one cell can be spread over */
 
 #define SS_PACK(x, y, r) ((uint32_t)(x) | ((uint32_t)(y) << 12) | ((uint32_t)(r) << 24))
