@@ -740,11 +740,12 @@ __device__ __forceinline__ void wave_sync()
 }
 
 /* libstdc++ std::sort(first, last, compareNodes) -- introsort: median-of-3 partitions down to 16
- * elements with a 2*lg(n) depth limit (heapsort beyond it), then one insertion pass -- executed by
- * ONE WAVE: the sequence of element moves is the sequential algorithm's (so equal keys land exactly
- * where libstdc++ leaves them), but the two inner scans of the partition and the
- * shift of the insertion step look at up to 64 elements per LDS round trip (ballot + count
- * trailing zeros) instead of one.  Control flow is wave-uniform. */
+ * elements with a 2*lg(n) depth limit (heapsort beyond it), then one insertion pass.  The partition
+ * loop is executed by ONE WAVE: the sequence of element moves is the sequential algorithm's (so
+ * equal keys land exactly where libstdc++ leaves them), but the two inner scans of a partition look
+ * at up to 64 elements per LDS round trip (ballot + count trailing zeros) instead of one; control
+ * flow is wave-uniform.  The insertion pass is done by the whole workgroup as a rank computation
+ * (sort_final_rank). */
 __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src_lane)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src_lane);
@@ -752,48 +753,6 @@ __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src_lane)
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ void wave_unguarded_linear_insert(uint64_t *a, int last, int lane)
-{
-    const uint64_t val = a[last]; /* uniform address: broadcast read */
-    int pos = last;
-    for (;;) {
-        const int i = pos - 1 - lane;
-        const uint64_t v = a[i < 0 ? 0 : i];
-        const bool shift = i >= 0 && item_less(val, v);
-        const uint64_t m = __ballot(!shift);
-        const int run = m ? (int)__builtin_ctzll(m) : WAVE; /* elements to move right by one */
-        if (lane < run) a[i + 1] = v;
-        pos -= run;
-        if (run < WAVE) break;
-    }
-    wave_sync();
-    if (lane == 0) a[pos] = val;
-    wave_sync();
-}
-
-__device__ void wave_insertion_sort(uint64_t *a, int first, int last, int lane)
-{
-    if (first == last) return;
-    for (int i = first + 1; i != last; ++i) {
-        const uint64_t val = a[i], head = a[first];
-        if (item_less(val, head)) {
-            /* move_backward(first, i, i + 1); *first = val -- at most 16 elements here */
-            for (int top = i; top > first; top -= WAVE) {
-                const int k = top - 1 - lane;
-                uint64_t v = 0;
-                if (k >= first) v = a[k];
-                wave_sync();
-                if (k >= first) a[k + 1] = v;
-                wave_sync();
-            }
-            if (lane == 0) a[first] = val;
-            wave_sync();
-        } else
-            wave_unguarded_linear_insert(a, i, lane);
-    }
-}
-
-/* std::sort(a, a + n, compareNodes) by the 64 lanes of one wave */
 /* `stack`: 64 words of LDS for the pending right-hand ranges (first | last << 12 | depth << 24); a local array
  * would be indexed dynamically and live in scratch memory */
 __device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane, uint32_t *stack)
@@ -869,11 +828,29 @@ __device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane
         }
     }
     wave_sync();
-    if (n > 16) {
-        wave_insertion_sort(a, 0, 16, lane);
-        for (int i = 16; i != n; ++i) wave_unguarded_linear_insert(a, i, lane);
-    } else
-        wave_insertion_sort(a, 0, n, lane);
+}
+
+/* __final_insertion_sort, without inserting anything.  After the loop above every range longer than 16 has been
+ * partitioned (or heap-sorted), so the array is a sequence of blocks of <= 16 elements with every key of a block <=
+ * every key of the next.  libstdc++'s final pass is an insertion sort whose inner loop moves an element left only
+ * past STRICTLY greater ones: it is stable, and no element can cross into a block of smaller-or-equal keys.  Its
+ * result is therefore the stable sort by key of the array as the loop left it:
+ *     final position of a[i] = #{j : key_j < key_i} + #{j < i : key_j == key_i},
+ * which every thread of the caller computes for its own elements (n broadcast reads of LDS each) instead of one
+ * wave shifting elements one insertion at a time -- the insertions were half of the quadtree kernel's time.
+ * `tmp` is a second array of n items; the caller separates the two phases with its barrier. */
+__device__ __forceinline__ void sort_final_rank(const uint64_t *a, uint64_t *tmp, int n, int tid, int n_threads)
+{
+    for (int i = tid; i < n; i += n_threads) {
+        const uint64_t v = a[i];
+        const uint64_t key = v >> 20;
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const uint64_t kj = a[j] >> 20;
+            rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+        }
+        tmp[rank] = v;
+    }
 }
 
 /* The first nodes of a tree live in LDS, later ones in the global table.  The cache is kept small on purpose:
@@ -999,7 +976,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                                                   ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
                                                   uint32_t *__restrict__ sel, ss_level_state *__restrict__ state, int items_cap)
 {
-    /* dynamic LDS, sized by the launch to the largest per-level list of the geometry (items_cap entries): LDS a tree
+    /* dynamic LDS, sized by the launch to the largest per-level list of the geometry (2 x items_cap entries: the sort
+     * array and the target of its final rank pass): LDS a tree
      * holds is LDS the other batches' FAST blocks cannot use while it is resident */
     extern __shared__ uint64_t items[];
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
@@ -1185,6 +1163,10 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                 __syncthreads();
                 if (wave == 0) std_sort_items_wave(items, n_prev, lane, sort_stack);
                 __syncthreads();
+                sort_final_rank(items, items + items_cap, n_prev, (int)threadIdx.x, QT_THREADS);
+                __syncthreads();
+                for (int j = threadIdx.x; j < n_prev; j += QT_THREADS) items[j] = items[items_cap + j];
+                __syncthreads();
                 n_nxt = 0;
                 int dummy = 0;
                 const bool stopped = sweep([&](int k) { return (int)((uint32_t)items[n_prev - 1 - k] & 0xFFFFFu); }, n_prev, true,
@@ -1244,9 +1226,12 @@ __global__ __launch_bounds__(64) void k_debug_sort(uint64_t *__restrict__ data, 
     for (int i = lane; i < n; i += WAVE) items[i] = data[i];
     wave_sync();
     __shared__ uint32_t sort_stack[64];
+    __shared__ uint64_t sorted[QT_MAX_ITEMS];
     std_sort_items_wave(items, n, lane, sort_stack);
     wave_sync();
-    for (int i = lane; i < n; i += WAVE) data[i] = items[i];
+    sort_final_rank(items, sorted, n, lane, WAVE);
+    wave_sync();
+    for (int i = lane; i < n; i += WAVE) data[i] = sorted[i];
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1749,7 +1734,7 @@ void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uin
     int need = 0;
     for (int l = 0; l < hg.n_levels; l++) need = hg.lv[l].item_cap > need ? hg.lv[l].item_cap : need;
     need = (need + 63) & ~63;
-    hipLaunchKernelGGL(k_quadtree, dim3(n_frames, hg.n_levels), dim3(QT_THREADS), (size_t)need * sizeof(uint64_t), s, dg, cand, qbuf0,
+    hipLaunchKernelGGL(k_quadtree, dim3(n_frames, hg.n_levels), dim3(QT_THREADS), (size_t)need * 2 * sizeof(uint64_t), s, dg, cand, qbuf0,
                        qbuf1, nodes, lists, sel, state, need);
 }
 
