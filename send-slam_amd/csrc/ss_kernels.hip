@@ -754,10 +754,11 @@ __device__ __forceinline__ uint64_t lane_bcast64(uint64_t v, int src_lane)
 }
 
 /* `stack`: 64 words of LDS for the pending right-hand ranges (first | last << 12 | depth << 24); a local array
- * would be indexed dynamically and live in scratch memory */
-__device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane, uint32_t *stack)
+ * would be indexed dynamically and live in scratch memory.  `pos`: scratch LDS for 2 x pos_half u16 (>= n each). */
+__device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane, uint32_t *stack, uint16_t *pos, int pos_half)
 {
     if (n <= 0) return;
+    const uint64_t lt = lanemask_lt();
     int lg = 0;
     for (unsigned v = (unsigned)n; v > 1; v >>= 1) lg++;
     int sp = 1;
@@ -793,32 +794,50 @@ __device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane
                 wave_sync();
             }
             const uint64_t pivot = a[first];
-            int lo = first + 1, hi = last; /* __unguarded_partition */
-            for (;;) {
-                uint64_t v_lo, v_hi;
-                for (;;) { /* while (a[lo] < pivot) ++lo; */
-                    const int i = lo + lane;
-                    const uint64_t v = a[i < last ? i : last - 1];
-                    const uint64_t m = __ballot(i >= last || !item_less(v, pivot));
-                    const int adv = m ? (int)__builtin_ctzll(m) : WAVE;
-                    lo += adv;
-                    if (adv < WAVE) { v_lo = lane_bcast64(v, adv); break; }
-                }
-                --hi;
-                for (;;) { /* while (pivot < a[hi]) --hi; */
-                    const int i = hi - lane;
-                    const uint64_t v = a[i > first ? i : first];
-                    const uint64_t m = __ballot(i <= first || !item_less(pivot, v));
-                    const int adv = m ? (int)__builtin_ctzll(m) : WAVE;
-                    hi -= adv;
-                    if (adv < WAVE) { v_hi = lane_bcast64(v, adv); break; }
-                }
-                if (!(lo < hi)) break;
-                wave_sync();
-                if (lane == 0) { a[lo] = v_hi; a[hi] = v_lo; }
-                wave_sync();
-                ++lo;
+            /* __unguarded_partition(first + 1, last, pivot), all of its swaps at once.  The left pointer stops at
+             * the positions whose element is not < pivot, in ascending order; the right pointer at those whose
+             * element is not > pivot, in descending order; neither ever reads a position the other side has
+             * written before the two meet.  So swap k exchanges the k-th stop of each side for as long as the
+             * left one is left of the right one, and the returned cut is the first position after the last left
+             * stop used that holds an element not < pivot: the next left stop or the last right stop used,
+             * whichever comes first.  `pos` (scratch LDS, u16) lists the stops: left ones from the front, right
+             * ones -- ascending -- from n_cap. */
+            uint16_t *posL = pos, *posR = pos + pos_half;
+            int nL = 0, nR = 0;
+            for (int base = first + 1; base < last; base += WAVE) {
+                const int p = base + lane;
+                const bool in = p < last;
+                const uint64_t v = a[in ? p : last - 1];
+                const bool fl = in && !item_less(v, pivot), fr = in && !item_less(pivot, v);
+                const uint64_t ml = __ballot(fl), mr = __ballot(fr);
+                if (fl) posL[nL + __popcll(ml & lt)] = (uint16_t)p;
+                if (fr) posR[nR + __popcll(mr & lt)] = (uint16_t)p;
+                nL += __popcll(ml);
+                nR += __popcll(mr);
             }
+            wave_sync();
+            const int n_both = imin(nL, nR);
+            int n_swaps = 0;
+            for (int base = 0; base < n_both; base += WAVE) {
+                const int k = base + lane;
+                const bool ok = k < n_both && posL[k] < posR[nR - 1 - k];
+                const uint64_t m = __ballot(ok);
+                n_swaps += __popcll(m);
+                if (m != ~0ull) break; /* the predicate is monotone in k */
+            }
+            for (int base = 0; base < n_swaps; base += WAVE) {
+                const int k = base + lane;
+                if (k < n_swaps) {
+                    const int pl = posL[k], pr = posR[nR - 1 - k];
+                    const uint64_t vl = a[pl], vr = a[pr];
+                    a[pl] = vr;
+                    a[pr] = vl;
+                }
+            }
+            wave_sync();
+            int lo = n_swaps < nL ? (int)posL[n_swaps] : last;
+            if (n_swaps > 0) lo = imin(lo, (int)posR[nR - n_swaps]);
+            lo = rfl(lo);
             if (sp < 64) {
                 if (lane == 0) stack[sp] = (uint32_t)lo | ((uint32_t)last << 12) | ((uint32_t)depth << 24);
                 wave_sync();
@@ -1161,7 +1180,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                     items[j] = ((uint64_t)(uint32_t)nd.cnt << 32) | ((uint64_t)nd.x0 << 20) | (uint32_t)idx;
                 }
                 __syncthreads();
-                if (wave == 0) std_sort_items_wave(items, n_prev, lane, sort_stack);
+                if (wave == 0) std_sort_items_wave(items, n_prev, lane, sort_stack, (uint16_t *)(items + items_cap), items_cap);
                 __syncthreads();
                 sort_final_rank(items, items + items_cap, n_prev, (int)threadIdx.x, QT_THREADS);
                 __syncthreads();
@@ -1227,7 +1246,7 @@ __global__ __launch_bounds__(64) void k_debug_sort(uint64_t *__restrict__ data, 
     wave_sync();
     __shared__ uint32_t sort_stack[64];
     __shared__ uint64_t sorted[QT_MAX_ITEMS];
-    std_sort_items_wave(items, n, lane, sort_stack);
+    std_sort_items_wave(items, n, lane, sort_stack, (uint16_t *)sorted, QT_MAX_ITEMS);
     wave_sync();
     sort_final_rank(items, sorted, n, lane, WAVE);
     wave_sync();
