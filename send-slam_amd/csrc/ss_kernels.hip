@@ -995,8 +995,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                                                   ss_qnode *__restrict__ nodes_all, int32_t *__restrict__ lists_all,
                                                   uint32_t *__restrict__ sel, ss_level_state *__restrict__ state, int items_cap)
 {
-    /* dynamic LDS, sized by the launch to the largest per-level list of the geometry (2 x items_cap entries: the sort
-     * array and the target of its final rank pass): LDS a tree
+    /* dynamic LDS, sized by the launch to the largest per-level list of the geometry (2 x items_cap sort entries -- the array and
+     * the target of its final rank pass -- and the two expandable-node lists of items_cap ints): LDS a tree
      * holds is LDS the other batches' FAST blocks cannot use while it is resident */
     extern __shared__ uint64_t items[];
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
@@ -1028,8 +1028,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
     q.size = 0;
     q.error = 0;
     /* two expandable-node lists of item_cap ints each, swapped per pass */
-    int32_t *list_a = lists_all + ((size_t)frame * g->item_total + L.item_base) * 2;
-    int32_t *list_b = list_a + L.item_cap;
+    /* ... in LDS behind the sort arrays (items_cap >= every level's item_cap): reading the next node to divide is
+     * then not a global-memory round trip at the head of every step's dependency chain */
+    (void)lists_all;
+    int32_t *list_a = (int32_t *)(items + 2 * items_cap);
+    int32_t *list_b = list_a + items_cap;
     const int list_cap = L.item_cap;
 
     /* roots: vpIniNodes[kp.pt.x / hX]; list order r0, r1, ... == descending creation index,
@@ -1753,7 +1756,7 @@ void ssk_quadtree(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uin
     int need = 0;
     for (int l = 0; l < hg.n_levels; l++) need = hg.lv[l].item_cap > need ? hg.lv[l].item_cap : need;
     need = (need + 63) & ~63;
-    hipLaunchKernelGGL(k_quadtree, dim3(n_frames, hg.n_levels), dim3(QT_THREADS), (size_t)need * 2 * sizeof(uint64_t), s, dg, cand, qbuf0,
+    hipLaunchKernelGGL(k_quadtree, dim3(n_frames, hg.n_levels), dim3(QT_THREADS), (size_t)need * (2 * sizeof(uint64_t) + 2 * sizeof(int32_t)), s, dg, cand, qbuf0,
                        qbuf1, nodes, lists, sel, state, need);
 }
 
