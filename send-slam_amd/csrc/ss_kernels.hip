@@ -892,6 +892,37 @@ __device__ __forceinline__ ss_qnode *qt_node(const qt_ctx &q, int idx)
 {
     return idx < QT_LDS_NODES ? q.lds_nodes + idx : q.nodes + idx;
 }
+/* stores with the address space spelled out: through generic pointers they would be FLAT instructions, which
+ * count against the LDS counter too and would make lds_barrier() wait for global memory */
+typedef __attribute__((address_space(1))) uint32_t qt_gu32;
+typedef __attribute__((address_space(3))) uint32_t qt_lu32;
+static_assert(sizeof(ss_qnode) == 20, "ss_qnode is five dwords");
+__device__ __forceinline__ void qt_store_node(const qt_ctx &q, int idx, const ss_qnode &n)
+{
+    uint32_t w[5];
+    __builtin_memcpy(w, &n, sizeof(w));
+    if (idx < QT_LDS_NODES) {
+        qt_lu32 *p = (qt_lu32 *)(uint32_t *)(q.lds_nodes + idx);
+#pragma unroll
+        for (int i = 0; i < 5; i++) p[i] = w[i];
+    } else {
+        qt_gu32 *p = (qt_gu32 *)(uint32_t *)(q.nodes + idx);
+#pragma unroll
+        for (int i = 0; i < 5; i++) p[i] = w[i];
+    }
+}
+__device__ __forceinline__ void qt_store_flags(const qt_ctx &q, int idx, int flags)
+{
+    if (idx < QT_LDS_NODES) ((qt_lu32 *)(uint32_t *)(q.lds_nodes + idx))[4] = (uint32_t)flags;
+    else ((qt_gu32 *)(uint32_t *)(q.nodes + idx))[4] = (uint32_t)flags;
+}
+/* Workgroup barrier that orders LDS traffic only.  The steps of one sweep exchange their counts through LDS;
+ * what they write to global memory (moved records, child nodes) is read in the NEXT sweep, after a full
+ * __syncthreads().  Waiting for those stores to be acknowledged at every step was 40 % of the kernel's time. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 /* ExtractorNode::DivideNode is done in two steps so that the four waves of the workgroup can
  * divide four nodes of a pass at once and still number the children exactly as the sequential
@@ -936,7 +967,7 @@ __device__ __forceinline__ void qt_count(const qt_ctx &q, int idx, qt_div &d, in
 __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_div &d, const int c[4], int first_child)
 {
     const uint32_t *src = q.buf[d.b] + d.beg;
-    uint32_t *dst = q.buf[d.b ^ 1] + d.beg;
+    qt_gu32 *dst = (qt_gu32 *)(q.buf[d.b ^ 1] + d.beg); /* global_store, not flat_store (lds_barrier) */
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
     int run[4];
@@ -978,11 +1009,11 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
             ch.beg = d.beg + o[k];
             ch.cnt = c[k];
             ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((d.b ^ 1) << 2);
-            if (lane == 0) *qt_node(q, first_child + made) = ch;
+            if (lane == 0) qt_store_node(q, first_child + made, ch);
             made++;
         }
     }
-    if (lane == 0) qt_node(q, idx)->flags = d.flags & ~1; /* lNodes.erase */
+    if (lane == 0) qt_store_flags(q, idx, d.flags & ~1); /* lNodes.erase */
 }
 
 #ifndef QT_WAVES
@@ -1000,7 +1031,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
      * holds is LDS the other batches' FAST blocks cannot use while it is resident */
     extern __shared__ uint64_t items[];
     __shared__ ss_qnode lds_nodes[QT_LDS_NODES];
-    __shared__ int grp_cnt[QT_WAVES][4];
+    __shared__ __attribute__((aligned(16))) int grp_cnt[QT_WAVES][4];
     __shared__ int wave_alive[QT_WAVES];
     __shared__ uint32_t sort_stack[64];
     /* frame fastest: the eight XCDs take workgroups round-robin, and with the level fastest every level-0 tree
@@ -1101,24 +1132,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                 idx = rfl(node_at(k));
                 qt_count(q, idx, d, c);
             }
-            if (lane == 0) {
-                grp_cnt[wave][0] = c[0];
-                grp_cnt[wave][1] = c[1];
-                grp_cnt[wave][2] = c[2];
-                grp_cnt[wave][3] = c[3];
-            }
-            __syncthreads();
+            if (lane == 0) *(int4 *)&grp_cnt[wave][0] = make_int4(c[0], c[1], c[2], c[3]);
+            lds_barrier();
             /* every thread replays the sequential bookkeeping of the (up to) four divisions */
             int my_first_child = 0, my_first_nxt = 0;
             bool my_go = false;
-            for (int w = 0; w < QT_WAVES && k0 + w < n_list; w++) {
-                int made = 0, expandable = 0;
+            int4 cnts[QT_WAVES]; /* all counts first: one LDS latency, not one per quadrant of every wave */
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    const int cc = grp_cnt[w][qd];
-                    made += cc > 0;
-                    expandable += cc > 1;
-                }
+            for (int w = 0; w < QT_WAVES; w++) cnts[w] = *(const int4 *)&grp_cnt[w][0];
+#pragma unroll
+            for (int w = 0; w < QT_WAVES; w++) {
+                if (k0 + w >= n_list) break;
+                const int made = (cnts[w].x > 0) + (cnts[w].y > 0) + (cnts[w].z > 0) + (cnts[w].w > 0);
+                const int expandable = (cnts[w].x > 1) + (cnts[w].y > 1) + (cnts[w].z > 1) + (cnts[w].w > 1);
                 if (q.n_nodes + 4 > q.node_cap || n_nxt + expandable > list_cap) {
                     q.error = -5;
                     break;
@@ -1150,8 +1176,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
+        __syncthreads(); /* the sweep's global stores are visible to the whole workgroup from here */
         return stopped;
     };
 
