@@ -864,9 +864,15 @@ __device__ __forceinline__ void sort_final_rank(const uint64_t *a, uint64_t *tmp
         const uint64_t v = a[i];
         const uint64_t key = v >> 20;
         int rank = 0;
-        for (int j = 0; j < n; j++) {
-            const uint64_t kj = a[j] >> 20;
-            rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+        for (int j0 = 0; j0 < n; j0 += 8) { /* eight broadcast reads in flight */
+            uint64_t kj[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) kj[u] = a[imin(j0 + u, n - 1)] >> 20;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u;
+                rank += (j < n && (kj[u] < key || (kj[u] == key && j < i))) ? 1 : 0;
+            }
         }
         tmp[rank] = v;
     }
