@@ -882,7 +882,9 @@ __device__ __forceinline__ void sort_final_rank(const uint64_t *a, uint64_t *tmp
  * quadtree blocks share CUs with the FAST / match blocks of the other batches in flight, and every KB they hold
  * is a KB those cannot use (block LDS 37 KB -> 17.5 KB: +4 % frames/s, quadtree time unchanged; shrinking the
  * sort buffer as well packs the trees onto fewer CUs and loses it again). */
+#ifndef QT_LDS_NODES
 #define QT_LDS_NODES 64
+#endif
 
 struct qt_ctx {
     uint32_t *buf[2];
