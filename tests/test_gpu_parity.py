@@ -501,6 +501,46 @@ def test_ss_track_poses_vs_oracle_pipeline_and_truth(oracle):
     assert max(np.abs(got[t]["quaternion"][:3]).max() for t in ok) < 5e-3
 
 
+def test_contexts_are_independent_across_host_threads(oracle):
+    """"Distinct contexts are independent" (include/sendslam_orb.h): four host threads, one context each, different
+    image sizes and feature counts, interleaved extract / match / track calls -- every result equals the oracle's."""
+    import threading
+    cases = [(70, 640, 480, 800), (71, 800, 600, 1250), (72, 333, 517, 500), (73, 1280, 720, 2000)]
+    expected, got, errors = {}, {}, []
+    for seed, w, h, nf in cases:
+        img0, img1 = synth.frame(seed, w, h, 0), synth.frame(seed, w, h, 1)
+        p = oracle.default_params(n_features=nf)
+        k0, d0, _ = oracle.extract(img0, p)
+        k1, d1, _ = oracle.extract(img1, p)
+        expected[seed] = (k0, d0, k1, d1, oracle.match(d1, d0))
+
+    def work(seed, w, h, nf):
+        try:
+            img0, img1 = synth.frame(seed, w, h, 0), synth.frame(seed, w, h, 1)
+            with binding.OrbContext(0, n_features=nf) as ctx:
+                out = []
+                for _ in range(6):
+                    k0, d0, _ = ctx.extract(img0)
+                    k1, d1, _ = ctx.extract(img1)
+                    out.append((k0, d0, k1, d1, ctx.match(d1, d0)))
+                got[seed] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append((seed, repr(e)))
+
+    threads = [threading.Thread(target=work, args=c) for c in cases]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    for seed, *_ in cases:
+        ek0, ed0, ek1, ed1, em = expected[seed]
+        for k0, d0, k1, d1, m in got[seed]:
+            assert k0.tobytes() == ek0.tobytes() and np.array_equal(d0, ed0)
+            assert k1.tobytes() == ek1.tobytes() and np.array_equal(d1, ed1)
+            assert all(np.array_equal(a, b) for a, b in zip(m, em))
+
+
 def test_contexts_do_not_leak_device_memory():
     import torch
     img = synth.frame(5, 640, 480)
