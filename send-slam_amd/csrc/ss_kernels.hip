@@ -424,24 +424,26 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         const int ly = (int)(list[e] >> 8) - 1, lx = (int)(list[e] & 0xFF) - 1;
         const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
         const int v = c[0];
-        int d[16];
+        /* max over arcs of min9(v - p) = v - (min over arcs of max9(p)) and max over arcs of min9(p - v) =
+         * (max over arcs of min9(p)) - v: the 16 differences are never formed */
+        int p[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - c[RDY[k] * (FT_WORDS * 4) + RDX[k]];
+        for (int k = 0; k < 16; k++) p[k] = c[RDY[k] * (FT_WORDS * 4) + RDX[k]];
         int lo3[16], hi3[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            lo3[k] = min3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-            hi3[k] = max3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+            lo3[k] = min3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+            hi3[k] = max3(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
         }
-        int dark = -256, bright = 256; /* max over arcs of min(d); min over arcs of max(d) */
+        int arc_hi = 256, arc_lo = -1; /* min over arcs of max9(p); max over arcs of min9(p) */
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
-            dark = max3(dark, min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]),
-                        min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
-            bright = min3(bright, max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]),
+            arc_hi = min3(arc_hi, max3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]),
                           max3(hi3[k + 1], hi3[(k + 4) & 15], hi3[(k + 7) & 15]));
+            arc_lo = max3(arc_lo, min3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]),
+                          min3(lo3[k + 1], lo3[(k + 4) & 15], lo3[(k + 7) & 15]));
         }
-        const int R = imax(dark, -bright);
+        const int R = imax(v - arc_hi, arc_lo - v);
         if (R > min_th) {
             out8[(ly + 1) * (FT_WORDS * 4) + 4 + lx] = (uint8_t)(R - 1);
             if ((unsigned)lx < SS_TILE_W && (unsigned)ly < SS_TILE_H2) corners[atomicAdd(&n_corner, 1)] = (uint16_t)((ly << 8) | lx);
