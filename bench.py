@@ -361,7 +361,7 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel_ms": dom["isolated_mean_ms"] if dom["isolated_GBps"] else dom["mean_ms"],
                     "timed_region_event_ms": dom["mean_ms"], "timed_region_event_GBps": dom["achieved_GBps"],
-                    "note": "integer-VALU-bound kernel (DESIGN.md section 5: 87 % of the measured VALU issue rate): the HBM "
+                    "note": "integer-VALU-bound kernel (DESIGN.md section 5: 86 % of the measured VALU issue rate): the HBM "
                             "fraction is reported because the contract asks for it, not because HBM limits it"}
 
     # the Hamming-match kernel against the resource that actually bounds it: integer VALU issue.
