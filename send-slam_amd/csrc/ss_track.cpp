@@ -567,11 +567,13 @@ int sst_pose_only(int n, const double *pts3d, const double *obs, const double *i
                 const double w = (robust && e2 > delta * delta) ? w0 * delta / std::sqrt(e2) : w0;
                 const double J0[6] = {x * y * iz2 * c.fx, -(1 + x * x * iz2) * c.fx, y * iz * c.fx, -iz * c.fx, 0, x * iz2 * c.fx};
                 const double J1[6] = {(1 + y * y * iz2) * c.fy, -x * y * iz2 * c.fy, -x * iz * c.fy, 0, -iz * c.fy, y * iz2 * c.fy};
-                for (int a = 0; a < 6; a++) {
+                for (int a = 0; a < 6; a++) { /* upper triangle only: the products are symmetric term by term */
                     b[a] -= w * (J0[a] * ex + J1[a] * ey);
-                    for (int cc = 0; cc < 6; cc++) H[6 * a + cc] += w * (J0[a] * J0[cc] + J1[a] * J1[cc]);
+                    for (int cc = a; cc < 6; cc++) H[6 * a + cc] += w * (J0[a] * J0[cc] + J1[a] * J1[cc]);
                 }
             }
+            for (int a = 1; a < 6; a++)
+                for (int cc = 0; cc < a; cc++) H[6 * a + cc] = H[6 * cc + a];
             for (int a = 0; a < 6; a++) H[7 * a] += lambda * (1.0 + H[7 * a]);
             if (!chol6_solve(H, b)) return -2;
             double dR[9], dt[3], Rn[9];
