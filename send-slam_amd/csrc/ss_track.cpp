@@ -226,6 +226,56 @@ double check_homography(const double *H21, const double *H12, int n, const doubl
     return score;
 }
 
+/* Smallest singular vector of a 4 x 4 system by inverse iteration on A^T A (Cholesky of the slightly shifted
+ * matrix, iterated to convergence): the same vector the Jacobi solver returns, ~20x cheaper, which matters because a
+ * frame triangulates every match that carries no map point yet.  false = did not converge (caller falls back). */
+bool null_vector4(const double *A, double *x)
+{
+    double M[16] = {0};
+    for (int r = 0; r < 4; r++)
+        for (int i = 0; i < 4; i++)
+            for (int j = i; j < 4; j++) M[4 * i + j] += A[4 * r + i] * A[4 * r + j];
+    const double shift = 1e-13 * (M[0] + M[5] + M[10] + M[15]);
+    if (!(shift > 0)) return false;
+    double L[16] = {0};
+    for (int j = 0; j < 4; j++) { /* M + shift I = L L^T */
+        double d = M[5 * j] + shift;
+        for (int k = 0; k < j; k++) d -= L[4 * j + k] * L[4 * j + k];
+        if (!(d > 0)) return false;
+        L[5 * j] = std::sqrt(d);
+        for (int i = j + 1; i < 4; i++) {
+            double v = M[4 * j + i];
+            for (int k = 0; k < j; k++) v -= L[4 * i + k] * L[4 * j + k];
+            L[4 * i + j] = v / L[5 * j];
+        }
+    }
+    double v[4] = {0.5, 0.5, 0.5, 0.5};
+    for (int it = 0; it < 60; it++) {
+        double y[4];
+        for (int i = 0; i < 4; i++) {
+            double t = v[i];
+            for (int k = 0; k < i; k++) t -= L[4 * i + k] * y[k];
+            y[i] = t / L[5 * i];
+        }
+        for (int i = 3; i >= 0; i--) {
+            double t = y[i];
+            for (int k = i + 1; k < 4; k++) t -= L[4 * k + i] * y[k];
+            y[i] = t / L[5 * i];
+        }
+        const double nrm = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
+        if (!(nrm > 0) || !std::isfinite(nrm)) return false;
+        double diff = 0, dot = 0;
+        for (int i = 0; i < 4; i++) { y[i] /= nrm; dot += y[i] * v[i]; }
+        const double sgn = dot < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < 4; i++) { const double w = sgn * y[i]; diff = std::max(diff, std::fabs(w - v[i])); v[i] = w; }
+        if (diff < 1e-15 && it > 0) {
+            for (int i = 0; i < 4; i++) x[i] = v[i];
+            return true;
+        }
+    }
+    return false;
+}
+
 /* linear triangulation with P = K [R | t]; returns false if the homogeneous weight vanishes */
 bool triangulate_dlt(const sst_camera &c, const double x1[2], const double x2[2], const double R1[9], const double t1[3],
                      const double R2[9], const double t2[3], double X[3])
@@ -250,7 +300,7 @@ bool triangulate_dlt(const sst_camera &c, const double x1[2], const double x2[2]
         A[12 + j] = x2[1] * P2[8 + j] - P2[4 + j];
     }
     double h[4];
-    null_vector(4, 4, A, h);
+    if (!null_vector4(A, h)) null_vector(4, 4, A, h);
     if (h[3] == 0 || !std::isfinite(h[3])) return false;
     X[0] = h[0] / h[3]; X[1] = h[1] / h[3]; X[2] = h[2] / h[3];
     return std::isfinite(X[0]) && std::isfinite(X[1]) && std::isfinite(X[2]);
