@@ -378,6 +378,20 @@ def main():
         int_roofline = {"kernel": "match", "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
                         "unit": "lane-ops/s", "frac": round(ach / peak, 4), "ops_per_pair": 19}
 
+    # the dominant kernel against the resource that bounds it: VALU issue.  Instruction count per launch from the
+    # committed PMC pass of this workload (profiles/r01_pmc_sq_mix.json, SQ_INSTS_VALU of a full-batch launch),
+    # duration live; peak = the measured issue rate (profiles/r01_peaks.json).
+    valu_roofline = None
+    mix_path = os.path.join(ROOT, "profiles", "r01_pmc_sq_mix.json")
+    if dom and dom.get("isolated_mean_ms") and os.path.exists(mix_path) and os.path.exists(ppath) and (B, w, h, nf) == (64, 1280, 720, 2000):
+        stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match", "orient_describe": "k_orient_describe"}.get(dom["name"])
+        insts = json.load(open(mix_path)).get(stage_kernel, {}).get("SQ_INSTS_VALU")
+        if insts:
+            peak = json.load(open(ppath))["xor_popc_lane_ops_per_s"]
+            ach = insts * 64 / (dom["isolated_mean_ms"] * 1e-3)
+            valu_roofline = {"kernel": dom["name"], "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
+                             "unit": "lane-ops/s", "frac": round(ach / peak, 4), "valu_wave_instructions_per_launch": insts}
+
     total_frames = B * a.steps * world
     out = {
         "metric": "frames/sec ORB extract+match @1280x720, 2000 kp/frame",
@@ -388,7 +402,7 @@ def main():
                    "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
-        "roofline": roofline, "int_valu_roofline": int_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+        "roofline": roofline, "valu_roofline": valu_roofline, "int_valu_roofline": int_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
         "single_frame_host_to_host_ms": None if single_frame_ms is None else round(single_frame_ms, 3),
         "track_frame_host_to_host_ms": None if track_ms is None else round(track_ms, 3), "track_ok_frames_of_14": track_ok,
     }
