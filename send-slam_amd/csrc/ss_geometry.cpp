@@ -123,6 +123,23 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
             g->umax[v] = v0;
             ++v0;
         }
+        /* the per-lane form of the same table: left half = u in [-d, -1], right half = u in [0, d] */
+        for (int lane = 0; lane < 64; lane++) {
+            const int row = lane & 31, half = lane >> 5;
+            int count = 0;
+            g->ic_u0[lane] = 0;
+            if (row <= 2 * SS_HALF_PATCH) {
+                const int d = g->umax[row < SS_HALF_PATCH ? SS_HALF_PATCH - row : row - SS_HALF_PATCH];
+                count = half ? d + 1 : d;
+                g->ic_u0[lane] = half ? 0 : -d;
+            }
+            for (int k = 0; k < 4; k++) {
+                uint32_t m = 0;
+                for (int b = 0; b < 4; b++)
+                    if (4 * k + b < count) m |= 0xFFu << (8 * b);
+                g->ic_mask[lane][k] = m;
+            }
+        }
     }
 
     tabs->rtab.clear();

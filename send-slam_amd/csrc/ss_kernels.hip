@@ -20,6 +20,7 @@
  * kernel takes the batch slot in blockIdx.y or .z so one launch covers a batch of frames.
  * Float steps are single IEEE operations (-ffp-contract=off, ss_float_steps.h).
  */
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
             const int idx = (int)threadIdx.x + 256 * it;
             const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
             const int gy = gy0 + r, gx = gx0 + 4 * c;
-            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < S.pitch) ? *(const uint32_t *)(src + (size_t)gy * S.pitch + gx) : 0u;
+            /* rows and pitches are far below 2^24 and a level below 2^32 bytes: v_mad_u32_u24 instead of a 64-bit multiply */
+            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < S.pitch) ? *(const uint32_t *)(src + (__umul24((uint32_t)gy, (uint32_t)S.pitch) + (uint32_t)gx)) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < ROUNDS; it++) {
@@ -201,12 +203,15 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int h0 = l0[rx[i].s0] * rx[i].a0 + l0[rx[i].s1] * rx[i].a1;
-            const int h1 = l1[rx[i].s0] * rx[i].a0 + l1[rx[i].s1] * rx[i].a1;
-            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            /* every factor is below 2^12 (taps), 2^8 (pixels) or 2^16 (h >> 4): the 24-bit multiplier (full rate) gives
+             * the same products as the 32-bit one (quarter rate) */
+            const int h0 = __mul24((int)l0[rx[i].s0], (int)rx[i].a0) + __mul24((int)l0[rx[i].s1], (int)rx[i].a1);
+            const int h1 = __mul24((int)l1[rx[i].s0], (int)rx[i].a0) + __mul24((int)l1[rx[i].s1], (int)rx[i].a1);
+            /* h >> 4 < 2^16 (the & is a no-op that lets the compiler see it: one v_bfe_u32, then the 24-bit multiplier) */
+            const int v = ((__mul24(b0, (int)(((uint32_t)h0 >> 4) & 0xFFFFu)) >> 16) + (__mul24(b1, (int)(((uint32_t)h1 >> 4) & 0xFFFFu)) >> 16) + 2) >> 2;
             out |= ((uint32_t)v & 0xFFu) << (8 * i);
         }
-        *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
+        *(uint32_t *)(base + D.off + (__umul24((uint32_t)dy, (uint32_t)D.pitch) + (uint32_t)dx4)) = out;
     }
 }
 
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     if (inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h) {
         /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
         const uint8_t *tile0 = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
-        const uint32_t off = (uint32_t)(ty * pitch + 4 * tx);
+        const uint32_t off = __umul24((uint32_t)ty, (uint32_t)pitch) + 4u * (uint32_t)tx;
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
             const int r = ty + (FT_THREADS / 16) * rr;
@@ -505,8 +510,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         const uint32_t out_b = __builtin_amdgcn_perm(vb[1], vb[0], 0x0C0C0602u) | __builtin_amdgcn_perm(vb[3], vb[2], 0x06020C0Cu);
         const int ya = y0 + 2 * ty;
         if (x0 + 4 * tx < pitch) {
-            if (ya < h) *(uint32_t *)(blur + fb + (size_t)ya * pitch + x0 + 4 * tx) = out_a;
-            if (ya + 1 < h) *(uint32_t *)(blur + fb + (size_t)(ya + 1) * pitch + x0 + 4 * tx) = out_b;
+            /* 24-bit multiply + 32-bit offset (a level is far below 2^32 bytes) instead of a 64-bit v_mad_i64_i32 */
+            const uint32_t o = __umul24((uint32_t)ya, (uint32_t)pitch) + (uint32_t)(x0 + 4 * tx);
+            if (ya < h) *(uint32_t *)(blur + fb + o) = out_a;
+            if (ya + 1 < h) *(uint32_t *)(blur + fb + (o + (uint32_t)pitch)) = out_b;
         }
     }
     if (score) {
@@ -1352,6 +1359,7 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
 /* pairs L, L+64, L+128, L+192; __ballot(t0 < t1) IS descriptor bytes 8k .. 8k+7 (bit i of  */
 /* byte j = test 8j+i).                                                                    */
 /* ------------------------------------------------------------------------------------ */
+static_assert(offsetof(ss_geom, ic_mask) % 16 == 0, "ic_mask is loaded as dwordx4");
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
 
 __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
@@ -1384,6 +1392,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     uint32_t pat[4]; /* this lane's four sample pairs of the pattern: independent of the keypoint, requested first */
 #pragma unroll
     for (int k = 0; k < 4; k++) pat[k] = *(const uint32_t *)(c_pattern + 4 * (lane + 64 * k));
+    /* this lane's share of the disc (row lane & 31, left or right half): first u and the byte masks of its <= 16 pixels */
+    const uint4 icm = ((const uint4 *)g->ic_mask)[lane];
+    const int u0 = g->ic_u0[lane];
     {
         const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
 #pragma unroll
@@ -1391,31 +1402,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             const int idx = lane + WAVE * it;
             if (idx < 31 * 10) {
                 const int r = idx / 10, c = idx - r * 10;
-                patch[r][c] = *(const uint32_t *)(p0 + (size_t)r * pitch + 4 * c);
+                patch[r][c] = *(const uint32_t *)(p0 + (__umul24((uint32_t)r, (uint32_t)pitch) + 4u * (uint32_t)c));
             }
         }
     }
     wave_sync();
-    int m10 = 0, m01 = 0;
+    int m10, m01;
     {
-        const int row = lane & 31, half = lane >> 5;
-        if (row < 31) {
-            const int v = row - SS_HALF_PATCH;
-            const int d = g->umax[v < 0 ? -v : v];
-            const uint8_t *p = (const uint8_t *)&patch[row][0] + (kx - px0);
-            const int u0 = half ? 0 : -d, u1 = half ? d : -1;
-            int rs = 0;
-            /* fixed 16 steps with the tail masked: the 16 LDS byte reads issue back to back and their latency is
-             * paid once, instead of once per step of a data-dependent loop (u0 + k stays inside the staged row) */
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int u = u0 + k;
-                const int val = u <= u1 ? (int)p[u] : 0;
-                m10 += u * val;
-                rs += val;
-            }
-            m01 = v * rs;
-        }
+        /* the lane's pixels are 16 consecutive bytes of its staged row starting at u0 (the tail masked off): five
+         * aligned dwords, four v_alignbyte, then m10 = sum u * I = u0 * sum I + sum k * I_k and m01 = v * sum I as
+         * eight v_dot4_u32_u8 -- integer sums, so the order of additions is free */
+        const int row = imin(lane & 31, 30); /* lanes 31 and 63 carry zero masks */
+        const int sb = (kx - px0) + u0;      /* 0 .. 18: byte offset in the staged row */
+        const uint32_t *rw = &patch[row][sb >> 2];
+        const uint32_t sh = (uint32_t)sb & 3u;
+        const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3], w4 = rw[4];
+        const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh) & icm.x, a1 = __builtin_amdgcn_alignbyte(w2, w1, sh) & icm.y;
+        const uint32_t a2 = __builtin_amdgcn_alignbyte(w3, w2, sh) & icm.z, a3 = __builtin_amdgcn_alignbyte(w4, w3, sh) & icm.w;
+        const uint32_t rs = __builtin_amdgcn_udot4(a0, 0x01010101u, __builtin_amdgcn_udot4(a1, 0x01010101u,
+                            __builtin_amdgcn_udot4(a2, 0x01010101u, __builtin_amdgcn_udot4(a3, 0x01010101u, 0u, false), false), false), false);
+        const uint32_t ws = __builtin_amdgcn_udot4(a0, 0x03020100u, __builtin_amdgcn_udot4(a1, 0x07060504u,
+                            __builtin_amdgcn_udot4(a2, 0x0B0A0908u, __builtin_amdgcn_udot4(a3, 0x0F0E0D0Cu, 0u, false), false), false), false);
+        m10 = __mul24(u0, (int)rs) + (int)ws;
+        m01 = __mul24((lane & 31) - SS_HALF_PATCH, (int)rs);
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -1425,19 +1434,24 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
 
     /* steered rBRIEF: the eight sample addresses of a lane first, then the eight byte loads together, then the
      * four ballots (the pattern words were requested before the IC stage) */
-    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx;
-    int off0[4], off1[4];
+    /* cvRound by the 1.5 * 2^23 trick: x + 12582912.f has the integer nearest to x (ties to even, like v_rndne) in its
+     * mantissa, bits = 0x4B400000 + round(x) for |x| < 2^22.  The row takes one subtraction to feed the 24-bit
+     * multiplier; the column keeps the bias, which moves into the (wave-uniform) base pointer */
+    constexpr float RN_MAGIC = 12582912.f;
+    constexpr int RN_BIAS = 0x4B400000;
+    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx - RN_BIAS;
+    uint32_t off0[4], off1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t pt = pat[k]; /* x0 y0 x1 y1 as int8 */
         const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
         const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        off0[k] = r0 * pitch + c0;
-        off1[k] = r1 * pitch + c1;
+        const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), RN_MAGIC)) - RN_BIAS;
+        const int c0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), RN_MAGIC));
+        const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), RN_MAGIC)) - RN_BIAS;
+        const int c1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), RN_MAGIC));
+        off0[k] = (uint32_t)(__mul24(r0, pitch) + c0); /* >= RN_BIAS - 20 * pitch > 0 */
+        off1[k] = (uint32_t)(__mul24(r1, pitch) + c1);
     }
     int t0[4], t1[4];
 #pragma unroll

@@ -90,6 +90,11 @@ typedef struct {
     int32_t item_total;
     int32_t tiles2_total;
     int32_t umax[16];
+    /* IC_Angle work split of k_orient_describe: lane = (row lane & 31, half lane >> 5) of the disc takes the pixels
+     * u0 .. u0 + 15 of its row, of which the bytes set in ic_mask[lane] are inside the disc (ss_geometry.cpp) */
+    int32_t ic_pad[2];       /* keeps ic_mask 16-byte aligned (loaded as dwordx4) */
+    uint32_t ic_mask[64][4];
+    int32_t ic_u0[64];
     ss_level lv[SS_MAX_LEVELS_];
 } ss_geom;
 
