@@ -1434,23 +1434,24 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
 
     /* steered rBRIEF: the eight sample addresses of a lane first, then the eight byte loads together, then the
      * four ballots (the pattern words were requested before the IC stage) */
-    /* cvRound by the 1.5 * 2^23 trick: x + 12582912.f has the integer nearest to x (ties to even, like v_rndne) in its
-     * mantissa, bits = 0x4B400000 + round(x) for |x| < 2^22.  The row takes one subtraction to feed the 24-bit
-     * multiplier; the column keeps the bias, which moves into the (wave-uniform) base pointer */
-    constexpr float RN_MAGIC = 12582912.f;
-    constexpr int RN_BIAS = 0x4B400000;
-    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx - RN_BIAS;
+    /* cvRound without v_rndne + v_cvt: x + (2^23 + 32) has ulp 1, so the sum is the integer nearest to x (ties to even,
+     * like cvRound) and its bits are 0x4B000020 + round(x) for |x| <= 32.  The low 24 bits, 32 + round(x), are what the
+     * 24-bit multiplier reads, and both biases move into the (wave-uniform) base pointer: two additions and one
+     * v_mad_i32_i24 per sample address */
+    constexpr float RN_MAGIC = 8388640.f;
+    constexpr int RN_BIAS = 0x4B000020;
+    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx - RN_BIAS - 32 * pitch;
     uint32_t off0[4], off1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const uint32_t pt = pat[k]; /* x0 y0 x1 y1 as int8 */
         const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
         const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
-        const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), RN_MAGIC)) - RN_BIAS;
+        const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), RN_MAGIC));
         const int c0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), RN_MAGIC));
-        const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), RN_MAGIC)) - RN_BIAS;
+        const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), RN_MAGIC));
         const int c1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), RN_MAGIC));
-        off0[k] = (uint32_t)(__mul24(r0, pitch) + c0); /* >= RN_BIAS - 20 * pitch > 0 */
+        off0[k] = (uint32_t)(__mul24(r0, pitch) + c0); /* (32 + row) * pitch + RN_BIAS + col: positive, below 2^31 */
         off1[k] = (uint32_t)(__mul24(r1, pitch) + c1);
     }
     int t0[4], t1[4];
