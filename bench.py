@@ -377,6 +377,16 @@ def main():
         ach = pairs * 19 / (mk["isolated_mean_ms"] * 1e-3)
         int_roofline = {"kernel": "match", "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
                         "unit": "lane-ops/s", "frac": round(ach / peak, 4), "ops_per_pair": 19}
+        # the same 19 instructions priced one by one (profiles/r01_valu_rates.json, profiles/tools/valu_rates.hip:
+        # v_xor_b32 issues at twice the rate of v_bcnt / v_med3 / v_min / v_lshl_or on this chip)
+        rpath = os.path.join(ROOT, "profiles", "r01_valu_rates.json")
+        if os.path.exists(rpath):
+            rates = json.load(open(rpath))
+            c = rates["cycles_per_wave64_instruction_per_simd"]
+            cyc = 8 * c["v_xor_b32"] + 8 * c["v_bcnt_u32_b32"] + c["v_lshl_or_b32"] + c["v_med3_u32"] + c["v_min_u32"]
+            pair_peak = rates["cus"] * 4 * rates["clock_mhz"] * 1e6 / cyc * 64
+            int_roofline["cycles_per_wave_pair_at_measured_instruction_costs"] = round(cyc, 1)
+            int_roofline["frac_at_measured_instruction_costs"] = round(pairs / (mk["isolated_mean_ms"] * 1e-3) / pair_peak, 4)
 
     # the dominant kernel against the resource that bounds it: VALU issue.  Instruction count per launch from the
     # committed PMC pass of this workload (profiles/r01_pmc_sq_mix.json, SQ_INSTS_VALU of a full-batch launch),

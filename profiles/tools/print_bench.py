@@ -1,0 +1,5 @@
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"])
+for k in d["kernels"]: print(k["name"], k.get("isolated_mean_ms"), k.get("mean_ms"))
+print(d.get("int_valu_roofline"))

@@ -42,6 +42,7 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
 /* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8
+#define SSK_MATCH_MFMA_MIN_QUERIES 128 /* from this many query rows on, ssk_match runs the matrix-core kernel */
 /* database-streaming form for n_query <= 8 and n_train >= 65536; false = not applicable */
 bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,
                       void *partial, size_t partial_bytes, int32_t *idx, uint16_t *d1, uint16_t *d2);

@@ -1605,6 +1605,235 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* K7 on the matrix cores.  Hamming distance IS a contraction: with descriptor bits spread to    */
+/* bytes, query bit -> +1 / -1 and train bit -> -1 / +1, the i8 dot product of two rows is        */
+/* 2 * hamming - 256, exactly, in int32.  v_mfma_i32_32x32x32_i8 does 32 x 32 pairs x 32 bits in   */
+/* one instruction, so the 16 XOR + popcount VALU per pair of k_match (profiles/r01_valu_rates.json: */
+/* v_bcnt issues at half rate) move to the otherwise idle MFMA pipe and the VALU keeps only the     */
+/* three instructions per pair that select best / second best.                                       */
+/* Block = 4 waves x 64 queries.  Queries are the B operand (column = lane & 31, resident in       */
+/* registers for the whole chunk), 32-row train tiles the A operand (expanded once per block into   */
+/* LDS through a 256-entry byte -> 8-byte table, rows padded to 272 B so ds_read_b128 is conflict   */
+/* free).  C/D layout: lane holds column (query) lane & 31 and train rows (r & 3) + 8 (r >> 2) +      */
+/* 4 (lane >> 5) of the tile in registers r = 0..15, so the selection runs per lane over registers  */
+/* with the same key = distance << 16 | local row as k_match, and lanes l / l + 32 merge at the end. */
+/* Same grid contract, same partial / final outputs as k_match.                                      */
+/* ------------------------------------------------------------------------------------ */
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+#define MM_ROW_BYTES 272
+#define MM_TILE 32
+#define MM_QBLOCK 256
+
+/* best / second best per lane, kept as FOUR independent (k1, k2) chains (register groups r >> 2) so the three
+ * dependent instructions of one element overlap with those of its neighbours; the chains merge once, at the end */
+__device__ __forceinline__ void mm_select(const v16i &acc, uint32_t kb0, uint32_t (&k1)[4], uint32_t (&k2)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        /* acc = 2 * hamming - 256; (acc + 256) << 15 = hamming << 16, local row in the low half */
+        const uint32_t key = ((uint32_t)acc[r] << 15) + (kb0 + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        const int c = r >> 2;
+        k2[c] = min(max(k1[c], k2[c]), max(min(k1[c], k2[c]), key));
+        k1[c] = min(k1[c], key);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
+                                                    const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
+                                                    int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
+                                                    int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
+                                                    int th, int rnum, int rden, int out_stride,
+                                                    match_partial *__restrict__ partial, int32_t *__restrict__ idx_out,
+                                                    uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+{
+    __shared__ uint2 lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[2][MM_TILE * MM_ROW_BYTES];
+    const int frame = blockIdx.z, chunk = blockIdx.y;
+    int tframe = frame + train_frame_shift;
+    if (tframe < 0) tframe = 0;
+    const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[tframe] : nt_fixed;
+    const bool excl = exclude_self_mode == 1 || (exclude_self_mode == 2 && tframe == frame);
+    const uint32_t *qf = query + (size_t)frame * q_frame_stride;
+    const uint32_t *tf = train + (size_t)tframe * t_frame_stride;
+    const int lane = lane_id(), col = lane & 31, half = lane >> 5;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int qbase = blockIdx.x * MM_QBLOCK + wave * 64; /* this wave's 64 queries: two 32-column B tiles */
+    const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
+    /* a block whose 256 query rows are all past the frame's count has nothing to select: no tiles */
+    const int n_tiles = (int)(blockIdx.x * MM_QBLOCK) < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
+
+    /* byte -> eight +1 / -1 bytes (bit i of the byte -> byte i): spread the nibble's bits to byte lanes by one
+     * multiplication, then 1 -> 0x01, 0 -> 0xFF */
+    {
+        const uint32_t t = threadIdx.x;
+        const uint32_t lo = ((t & 15u) * 0x204081u) & 0x01010101u, hi = ((t >> 4) * 0x204081u) & 0x01010101u;
+        lut[t] = make_uint2(lo | ((lo ^ 0x01010101u) * 0xFFu), hi | ((hi ^ 0x01010101u) * 0xFFu));
+    }
+    /* the packed word of the first tile this thread will expand: row t >> 3 of the tile, word t & 7 */
+    const int erow = (int)(threadIdx.x >> 3), eword = (int)(threadIdx.x & 7);
+    uint32_t wnext = (n_tiles > 0 && c0 + erow < c1) ? tf[(size_t)(c0 + erow) * 8 + eword] : 0u;
+    uint32_t qw[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int qi = qbase + 32 * u + col;
+        const uint4 *p = (const uint4 *)(qf + (size_t)(qi < nq ? qi : 0) * 8);
+        const uint4 a = p[0], b = p[1];
+        qw[u][0] = a.x; qw[u][1] = a.y; qw[u][2] = a.z; qw[u][3] = a.w;
+        qw[u][4] = b.x; qw[u][5] = b.y; qw[u][6] = b.z; qw[u][7] = b.w;
+    }
+    __syncthreads();
+    /* B fragments: k-step s, lane half h <-> bits 32 s + 16 h .. + 15 of the descriptor (the A rows in LDS use the
+     * same correspondence, which is all the contraction needs) */
+    v4i bq[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int sstep = 0; sstep < 8; sstep++) {
+            const uint32_t hw = (qw[u][sstep] >> (16 * half)) & 0xFFFFu;
+            const uint2 e0 = lut[hw & 0xFFu], e1 = lut[hw >> 8];
+            bq[u][sstep] = v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
+        }
+    auto expand = [&](int buf, uint32_t w) {
+        w = ~w; /* the train side carries the minus sign */
+        const uint2 e0 = lut[w & 0xFFu], e1 = lut[(w >> 8) & 0xFFu], e2 = lut[(w >> 16) & 0xFFu], e3 = lut[w >> 24];
+        uint4 *dst = (uint4 *)&tiles[buf][erow * MM_ROW_BYTES + eword * 32];
+        dst[0] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+        dst[1] = make_uint4(e2.x, e2.y, e3.x, e3.y);
+    };
+    auto load_word = [&](int tile) -> uint32_t {
+        const int j = c0 + tile * MM_TILE + erow;
+        return (tile < n_tiles && j < c1) ? tf[(size_t)j * 8 + eword] : 0u;
+    };
+    const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
+    const int q_lo = qbase, q_hi = qbase + 64;
+    /* Rows that must not compete -- past the end of the chunk, or the query itself in a self-match -- enter through
+     * the accumulator input: C = 2^15 there, which puts their keys above every real key (folded to "none" at the
+     * end).  Only the tiles that contain such rows (wave-uniform test) build a C vector; all others start from the
+     * inline constant 0, and the selection code is the same straight line for both. */
+    auto mfma_tile = [&](int tile, v16i &acc0, v16i &acc1) {
+        const int j0 = c0 + tile * MM_TILE;
+        const uint8_t *arow = &tiles[tile & 1][col * MM_ROW_BYTES + 16 * half];
+        const v4i a0 = *(const v4i *)arow;
+        const bool masked = j0 + MM_TILE > c1 || (excl && j0 < q_hi && j0 + MM_TILE > q_lo);
+        if (masked) {
+            const int rows_valid = c1 - j0, skip0 = excl ? qbase + col - j0 : -1, skip1 = excl ? qbase + 32 + col - j0 : -1;
+            v16i ci0, ci1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 4 * half + (r & 3) + 8 * (r >> 2);
+                ci0[r] = (row >= rows_valid || row == skip0) ? 32768 : 0;
+                ci1[r] = (row >= rows_valid || row == skip1) ? 32768 : 0;
+            }
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], ci0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], ci1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], v16i{0}, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], v16i{0}, 0, 0, 0);
+        }
+    };
+    auto mfma_rest = [&](int tile, v16i &acc0, v16i &acc1) {
+        const uint8_t *arow = &tiles[tile & 1][col * MM_ROW_BYTES + 16 * half];
+#pragma unroll
+        for (int sstep = 1; sstep < 8; sstep++) {
+            const v4i a = *(const v4i *)(arow + 32 * sstep);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][sstep], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][sstep], acc1, 0, 0, 0);
+        }
+    };
+    uint32_t k1[2][4], k2[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) k1[u][c] = k2[u][c] = 0xFFFFFFFFu;
+    auto select_tile = [&](int i, const v16i &acc0, const v16i &acc1) {
+        const uint32_t kb0 = (256u << 15) + (uint32_t)(i * MM_TILE + 4 * half);
+        mm_select(acc0, kb0, k1[0], k2[0]);
+        mm_select(acc1, kb0, k1[1], k2[1]);
+    };
+    /* software pipeline: the MFMAs of tile i + 1 and the selection from tile i's accumulators sit in one basic block,
+     * interleaved (one MFMA, then the VALU that fits in its 32 cycles), while tile i + 2 is expanded into the buffer
+     * tile i was read from; one barrier per tile */
+    v16i accA0, accA1, accB0, accB1;
+    if (n_tiles > 0) expand(0, wnext);
+    wnext = load_word(1);
+    __syncthreads();
+    if (n_tiles > 0 && active) {
+        mfma_tile(0, accA0, accA1);
+        mfma_rest(0, accA0, accA1);
+    }
+    if (n_tiles > 1) expand(1, wnext);
+    wnext = load_word(2);
+    __syncthreads();
+    auto phase_mid = [&](int i, const v16i &cur0, const v16i &cur1, v16i &nxt0, v16i &nxt1) {
+        if (active) {
+            mfma_tile(i + 1, nxt0, nxt1);
+            mfma_rest(i + 1, nxt0, nxt1);
+            select_tile(i, cur0, cur1);
+#pragma unroll
+            for (int g = 0; g < 14; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
+                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); /* nine VALU */
+            }
+        }
+        if (i + 2 < n_tiles) expand(i & 1, wnext);
+        wnext = load_word(i + 3);
+        __syncthreads();
+    };
+    bool done = n_tiles == 0;
+    for (int i = 0; i + 1 < n_tiles; i += 2) {
+        phase_mid(i, accA0, accA1, accB0, accB1);
+        if (i + 2 < n_tiles) {
+            phase_mid(i + 1, accB0, accB1, accA0, accA1);
+        } else {
+            if (active) select_tile(i + 1, accB0, accB1);
+            done = true;
+        }
+    }
+    if (!done && active) select_tile(n_tiles - 1, accA0, accA1);
+    /* fold the four chains of a lane: (a1 <= a2), (b1 <= b2) -> smallest two of the four */
+    uint32_t f1[2], f2[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        f1[u] = k1[u][0];
+        f2[u] = k2[u][0];
+#pragma unroll
+        for (int c = 1; c < 4; c++) {
+            const uint32_t lo = min(f1[u], k1[u][c]), hi = max(f1[u], k1[u][c]);
+            f2[u] = min(hi, min(f2[u], k2[u][c]));
+            f1[u] = lo;
+        }
+    }
+    /* lanes l and l + 32 hold the same query over different train rows */
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)f1[u], 32, 64), o2 = (uint32_t)__shfl_xor((int)f2[u], 32, 64);
+        uint32_t m1 = min(f1[u], o1), m2 = min(max(f1[u], o1), min(f2[u], o2));
+        if (m1 >= 0x20000000u) m1 = 0xFFFFFFFFu; /* only excluded rows were seen */
+        if (m2 >= 0x20000000u) m2 = 0xFFFFFFFFu;
+        const int qi = qbase + 32 * u + col;
+        if (half != 0 || qi >= out_stride) continue;
+        const bool qvalid = qi < nq;
+        const int d1 = (int)(m1 >> 16), d2 = (int)(m2 >> 16);
+        const int j1 = d1 == 0xFFFF ? -1 : c0 + (int)(m1 & 0xFFFFu);
+        if (n_chunks > 1) {
+            match_partial mp;
+            mp.d1 = (uint16_t)d1;
+            mp.d2 = (uint16_t)d2;
+            mp.j1 = j1;
+            partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
+        } else {
+            const size_t o = (size_t)frame * out_stride + qi;
+            const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
+            idx_out[o] = ok ? j1 : -1;
+            d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+            d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__restrict__ partial, const int32_t *__restrict__ nq_arr,
                                                      int nq_fixed, int n_chunks, int th, int rnum, int rden, int out_stride,
                                                      int32_t *__restrict__ idx_out, uint16_t *__restrict__ d1_out,
@@ -1829,16 +2058,19 @@ void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, co
 
 int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len)
 {
-    const int q_groups = (n_query_max + 63) / 64;
-    const long blocks_wanted = 16384; /* >> 256 CUs x 8 resident blocks: keeps the last partial round of blocks small */
+    /* the matrix-core kernel: 256 queries per block, 2 resident blocks per CU, and a per-block prologue (table, query
+     * fragments) that wants >= 8 tiles of 32 train rows behind it; the VALU kernel: 64 queries per block, 8 per CU */
+    const bool mfma = n_query_max >= SSK_MATCH_MFMA_MIN_QUERIES;
+    const int q_groups = mfma ? (n_query_max + MM_QBLOCK - 1) / MM_QBLOCK : (n_query_max + 63) / 64;
+    const long blocks_wanted = mfma ? 2048 : 16384; /* >> resident blocks: keeps the last partial round of blocks small */
     long chunks = (blocks_wanted + (long)q_groups * n_frames - 1) / ((long)q_groups * n_frames > 0 ? (long)q_groups * n_frames : 1);
-    const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave */
+    const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave / >= 8 tiles per block */
     if (chunks > max_chunks) chunks = max_chunks;
     const long min_chunks = ((long)n_train_max + 4 * 32768 - 1) / (4 * 32768); /* 16-bit local index */
     if (chunks < min_chunks) chunks = min_chunks;
     if (chunks < 1) chunks = 1;
     int len = (int)(((long)n_train_max + chunks - 1) / chunks);
-    len = (len + 3) & ~3;
+    len = mfma ? (len + MM_TILE - 1) & ~(MM_TILE - 1) : (len + 3) & ~3;
     if (len < 4) len = 4;
     *chunk_len = len;
     return (int)(((long)n_train_max + len - 1) / len > 0 ? ((long)n_train_max + len - 1) / len : 1);
@@ -1849,10 +2081,18 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
                int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
                int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames)
 {
-    dim3 grid((out_stride + 63) / 64, n_chunks, n_frames);
-    hipLaunchKernelGGL(k_match, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
-                       nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
-                       n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+    if (out_stride >= SSK_MATCH_MFMA_MIN_QUERIES) {
+        /* many queries: the matrix-core form (256 queries per block) */
+        dim3 grid((out_stride + MM_QBLOCK - 1) / MM_QBLOCK, n_chunks, n_frames);
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
+                           nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
+                           n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+    } else {
+        dim3 grid((out_stride + 63) / 64, n_chunks, n_frames);
+        hipLaunchKernelGGL(k_match, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
+                           nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
+                           n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+    }
     if (n_chunks >= 32 && n_frames == 1 && !nq_arr) {
         hipLaunchKernelGGL(k_match_merge_wide, dim3(out_stride), dim3(64), 0, s, (const match_partial *)partial, nq_fixed, n_chunks,
                            th, rnum, rden, out_stride, idx, d1, d2);
