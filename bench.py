@@ -32,6 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "send-slam_amd")):
 
 import numpy as np  # noqa: E402
 
+INT8_MFMA_PEAK_OPS = 5.0e15  # dense int8 MFMA, 2 x the 2.5e15 dense bf16 peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -364,34 +365,35 @@ def main():
                     "note": "integer-VALU-bound kernel (DESIGN.md section 5: 86 % of the measured VALU issue rate): the HBM "
                             "fraction is reported because the contract asks for it, not because HBM limits it"}
 
-    # the Hamming-match kernel against the resource that actually bounds it: integer VALU issue.
-    # Peak = register-resident XOR + popcount loop measured on this chip (profiles/r01_peaks.json,
-    # profiles/tools/peaks_probe.hip); work = 19 VALU lane-ops per (query, train) pair
-    # (8 xor + 8 popcount-accumulate + key, med3, min; the self-pair mask runs in 2 % of the waves).
-    int_roofline = None
+    # the Hamming-match kernel (k_match_mfma) against the two pipes it uses: the distance of a
+    # (query, train) pair is a 256-term i8 contraction on the matrix cores (512 int8 ops), the best / second-best
+    # selection stays on the VALU: per pair one v_lshl_add_u32 (key), one v_med3_u32, one v_min_u32, priced with the
+    # measured instruction costs (profiles/r01_valu_rates.json, profiles/tools/valu_rates.hip).  Peak int8 MFMA: 2 x
+    # the dense bf16 rate (MI355X_MICROARCH.md "Matrix cores": i8 = bf16 cycles at 2 x K) = 5.0e15 op/s.
+    match_roofline = None
     mk = next((k for k in kernels if k["name"] == "match"), None)
-    ppath = os.path.join(ROOT, "profiles", "r01_peaks.json")
-    if mk and mk.get("isolated_mean_ms") and os.path.exists(ppath):
-        peak = json.load(open(ppath))["xor_popc_lane_ops_per_s"]
+    rpath = os.path.join(ROOT, "profiles", "r01_valu_rates.json")
+    if mk and mk.get("isolated_mean_ms") and os.path.exists(rpath):
         pairs = B * float(nf) ** 2  # the quotas are saturated on these frames (2000 <= n <= 2024)
-        ach = pairs * 19 / (mk["isolated_mean_ms"] * 1e-3)
-        int_roofline = {"kernel": "match", "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
-                        "unit": "lane-ops/s", "frac": round(ach / peak, 4), "ops_per_pair": 19}
-        # the same 19 instructions priced one by one (profiles/r01_valu_rates.json, profiles/tools/valu_rates.hip:
-        # v_xor_b32 issues at twice the rate of v_bcnt / v_med3 / v_min / v_lshl_or on this chip)
-        rpath = os.path.join(ROOT, "profiles", "r01_valu_rates.json")
-        if os.path.exists(rpath):
-            rates = json.load(open(rpath))
-            c = rates["cycles_per_wave64_instruction_per_simd"]
-            cyc = 8 * c["v_xor_b32"] + 8 * c["v_bcnt_u32_b32"] + c["v_lshl_or_b32"] + c["v_med3_u32"] + c["v_min_u32"]
-            pair_peak = rates["cus"] * 4 * rates["clock_mhz"] * 1e6 / cyc * 64
-            int_roofline["cycles_per_wave_pair_at_measured_instruction_costs"] = round(cyc, 1)
-            int_roofline["frac_at_measured_instruction_costs"] = round(pairs / (mk["isolated_mean_ms"] * 1e-3) / pair_peak, 4)
+        t = mk["isolated_mean_ms"] * 1e-3
+        rates = json.load(open(rpath))
+        c = rates["cycles_per_wave64_instruction_per_simd"]
+        sel = c["v_lshl_add_u32"] + c["v_med3_u32"] + c["v_min_u32"]
+        simd_cycles_per_s = rates["cus"] * 4 * rates["clock_mhz"] * 1e6
+        valu_floor_ms = pairs / 64 * sel / simd_cycles_per_s * 1e3
+        mfma_floor_ms = pairs * 512 / INT8_MFMA_PEAK_OPS * 1e3
+        match_roofline = {"kernel": "match", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
+                          "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
+                          "kernel_ms": mk["isolated_mean_ms"], "mfma_floor_ms": round(mfma_floor_ms, 4),
+                          "valu_select_cycles_per_64_pairs": round(sel, 1), "valu_select_floor_ms": round(valu_floor_ms, 4),
+                          "frac_of_the_larger_floor": round(max(valu_floor_ms, mfma_floor_ms) / mk["isolated_mean_ms"], 4),
+                          "pairs_per_s": float(f"{pairs / t:.4g}")}
 
     # the dominant kernel against the resource that bounds it: VALU issue.  Instruction count per launch from the
     # committed PMC pass of this workload (profiles/r01_pmc_sq_mix.json, SQ_INSTS_VALU of a full-batch launch),
     # duration live; peak = the measured issue rate (profiles/r01_peaks.json).
     valu_roofline = None
+    ppath = os.path.join(ROOT, "profiles", "r01_peaks.json")
     mix_path = os.path.join(ROOT, "profiles", "r01_pmc_sq_mix.json")
     if dom and dom.get("isolated_mean_ms") and os.path.exists(mix_path) and os.path.exists(ppath) and (B, w, h, nf) == (64, 1280, 720, 2000):
         stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match", "orient_describe": "k_orient_describe"}.get(dom["name"])
@@ -412,7 +414,7 @@ def main():
                    "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
-        "roofline": roofline, "valu_roofline": valu_roofline, "int_valu_roofline": int_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+        "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
         "single_frame_host_to_host_ms": None if single_frame_ms is None else round(single_frame_ms, 3),
         "track_frame_host_to_host_ms": None if track_ms is None else round(track_ms, 3), "track_ok_frames_of_14": track_ok,
     }

@@ -15,7 +15,7 @@ key = sys.argv[2] if len(sys.argv) > 2 else "batch64_1280x720_n2000"
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = {"k_ingest_gray16": "ingest", "k_ingest": "ingest", "k_resize_lds": "resize", "k_fast_score": "fast_blur_nms",
          "k_bucket_gather": "bucket_gather", "k_cells_emit": "cells_emit", "k_quadtree": "quadtree", "k_slots": "slots",
-         "k_orient_describe": "orient_describe", "k_match": "match"}
+         "k_orient_describe": "orient_describe", "k_match": "match", "k_match_mfma": "match"}
 
 
 def newest(d, pattern):

@@ -156,7 +156,11 @@ def test_errors_leave_the_context_usable(oracle):
     assert e.value.code == binding.SS_ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (63, 64), (64, 65), (65, 63), (2000, 2000), (257, 5000), (40, 0)])
+# from 128 query rows on ssk_match runs the matrix-core kernel (256 queries per block, 64 per wave, 32-row train tiles):
+# sizes on both sides of each of those boundaries, empty / one-row / one-tile train sets, and the self-match of each
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2), (63, 64), (64, 65), (65, 63), (2000, 2000), (257, 5000), (40, 0),
+                                   (127, 127), (128, 128), (129, 31), (128, 1), (255, 33), (256, 256), (300, 0),
+                                   (321, 321), (512, 95), (1000, 4097)])
 def test_match_ragged_sizes_vs_oracle(oracle, nq, nt):
     rng = np.random.default_rng(nq * 7919 + nt)
     q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
