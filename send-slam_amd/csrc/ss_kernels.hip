@@ -2066,7 +2066,9 @@ int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_
     long chunks = (blocks_wanted + (long)q_groups * n_frames - 1) / ((long)q_groups * n_frames > 0 ? (long)q_groups * n_frames : 1);
     const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave / >= 8 tiles per block */
     if (chunks > max_chunks) chunks = max_chunks;
-    const long min_chunks = ((long)n_train_max + 4 * 32768 - 1) / (4 * 32768); /* 16-bit local index */
+    /* 16-bit local row index in the keys: per quarter-chunk of a wave in k_match, per chunk in k_match_mfma */
+    const long max_len = mfma ? 65536 : 4 * 32768;
+    const long min_chunks = ((long)n_train_max + max_len - 1) / max_len;
     if (chunks < min_chunks) chunks = min_chunks;
     if (chunks < 1) chunks = 1;
     int len = (int)(((long)n_train_max + chunks - 1) / chunks);

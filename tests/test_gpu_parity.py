@@ -199,6 +199,33 @@ def test_match_large_database_chunked(oracle):
     assert got[1][7] == 0 and got[2][7] == 0 and got[1][11] == 0 and got[0][11] == 149999
 
 
+def test_match_config5_full_database_chunks_at_the_index_limit(oracle):
+    # BASELINE.json config 5 at full size: 2000 query descriptors against 20 M rows (640 MB).  The chunk planner
+    # then hands the matrix-core kernel chunks at its 16-bit local-row limit (65 376 rows), the case no smaller
+    # database reaches; ties are planted on both sides of chunk boundaries and at the two ends.  The oracle checks a
+    # subset of the (independent) queries.
+    rng = np.random.default_rng(2025)
+    nq, nt = 2000, 20_000_000
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    for pos in (65375, 65376, 130751, 130752, 19_999_999):
+        t[pos] = q[3]           # first of five exact copies must win, d2 == 0
+    t[0] = q[1999]
+    t[19_999_998] = q[1999]
+    t[65535], t[65536] = q[64], q[64]
+    t[65535, 0] ^= 1            # distance 1 just below a 2^16 row index, distance 0 just above it
+    sel = np.array([0, 1, 2, 3, 63, 64, 65, 255, 256, 1000, 1998, 1999])
+    with binding.OrbContext(0) as ctx:
+        got = ctx.match(q, t, th=256, ratio_num=10)
+        raw = ctx.match(q, t, th=-1, ratio_num=10)  # raw mode: the best row even where the ratio test rejects a tie
+    want = oracle.match(np.ascontiguousarray(q[sel]), t, th=256, ratio_num=10)
+    for a, b, name in zip(got, want, ("idx", "d1", "d2")):
+        assert np.array_equal(a[sel], b), name
+    assert got[0][3] == -1 and got[1][3] == 0 and got[2][3] == 0 and raw[0][3] == 65375
+    assert got[0][1999] == -1 and got[2][1999] == 0 and raw[0][1999] == 0
+    assert got[0][64] == 65536 and got[1][64] == 0 and got[2][64] == 1
+
+
 def test_batch_device_path_matches_single_frame_path(oracle):
     import torch
     w, h, nf, B = 640, 480, 1000, 5
