@@ -1624,7 +1624,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 #define MM_ROW_BYTES 272
 #define MM_TILE 32
-#define MM_QBLOCK 256
+#ifndef MM_NU
+#define MM_NU 1 /* 32-query B tiles per wave: 1 = 117 VGPRs, four waves per SIMD; 2 = 198 VGPRs, two (measured: 1 is as fast alone and 2 % faster with four batches in flight -- it leaves room next to the other kernels) */
+#endif
+#define MM_QBLOCK (128 * MM_NU)
 
 /* best / second best per lane, kept as FOUR independent (k1, k2) chains (register groups r >> 2) so the three
  * dependent instructions of one element overlap with those of its neighbours; the chains merge once, at the end */
@@ -1640,7 +1643,7 @@ __device__ __forceinline__ void mm_select(const v16i &acc, uint32_t kb0, uint32_
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
+__global__ __launch_bounds__(256, MM_NU == 2 ? 2 : 4) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
                                                     const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                     int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                     int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
@@ -1660,7 +1663,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
     const uint32_t *tf = train + (size_t)tframe * t_frame_stride;
     const int lane = lane_id(), col = lane & 31, half = lane >> 5;
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int qbase = blockIdx.x * MM_QBLOCK + wave * 64; /* this wave's 64 queries: two 32-column B tiles */
+    const int qbase = blockIdx.x * MM_QBLOCK + wave * (32 * MM_NU); /* this wave's queries: MM_NU 32-column B tiles */
     const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
     /* a block whose 256 query rows are all past the frame's count has nothing to select: no tiles */
     const int n_tiles = (int)(blockIdx.x * MM_QBLOCK) < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
@@ -1677,7 +1680,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
     uint32_t wnext = (n_tiles > 0 && c0 + erow < c1) ? tf[(size_t)(c0 + erow) * 8 + eword] : 0u;
     uint32_t qw[2][8];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < MM_NU; u++) {
         const int qi = qbase + 32 * u + col;
         const uint4 *p = (const uint4 *)(qf + (size_t)(qi < nq ? qi : 0) * 8);
         const uint4 a = p[0], b = p[1];
@@ -1689,7 +1692,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
      * same correspondence, which is all the contraction needs) */
     v4i bq[2][8];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < MM_NU; u++)
 #pragma unroll
         for (int sstep = 0; sstep < 8; sstep++) {
             const uint32_t hw = (qw[u][sstep] >> (16 * half)) & 0xFFFFu;
@@ -1708,7 +1711,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
         return (tile < n_tiles && j < c1) ? tf[(size_t)j * 8 + eword] : 0u;
     };
     const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
-    const int q_lo = qbase, q_hi = qbase + 64;
+    const int q_lo = qbase, q_hi = qbase + 32 * MM_NU;
     /* Rows that must not compete -- past the end of the chunk, or the query itself in a self-match -- enter through
      * the accumulator input: C = 2^15 there, which puts their keys above every real key (folded to "none" at the
      * end).  Only the tiles that contain such rows (wave-uniform test) build a C vector; all others start from the
@@ -1728,10 +1731,10 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
                 ci1[r] = (row >= rows_valid || row == skip1) ? 32768 : 0;
             }
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], ci0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], ci1, 0, 0, 0);
+            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], ci1, 0, 0, 0);
         } else {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], v16i{0}, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], v16i{0}, 0, 0, 0);
+            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], v16i{0}, 0, 0, 0);
         }
     };
     auto mfma_rest = [&](int tile, v16i &acc0, v16i &acc1) {
@@ -1740,7 +1743,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
         for (int sstep = 1; sstep < 8; sstep++) {
             const v4i a = *(const v4i *)(arow + 32 * sstep);
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][sstep], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][sstep], acc1, 0, 0, 0);
+            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][sstep], acc1, 0, 0, 0);
         }
     };
     uint32_t k1[2][4], k2[2][4];
@@ -1751,7 +1754,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
     auto select_tile = [&](int i, const v16i &acc0, const v16i &acc1) {
         const uint32_t kb0 = (256u << 15) + (uint32_t)(i * MM_TILE + 4 * half);
         mm_select(acc0, kb0, k1[0], k2[0]);
-        mm_select(acc1, kb0, k1[1], k2[1]);
+        if (MM_NU > 1) mm_select(acc1, kb0, k1[1], k2[1]);
     };
     /* software pipeline: the MFMAs of tile i + 1 and the selection from tile i's accumulators sit in one basic block,
      * interleaved (one MFMA, then the VALU that fits in its 32 cycles), while tile i + 2 is expanded into the buffer
@@ -1773,7 +1776,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
             mfma_rest(i + 1, nxt0, nxt1);
             select_tile(i, cur0, cur1);
 #pragma unroll
-            for (int g = 0; g < 14; g++) {
+            for (int g = 0; g < 8 * MM_NU - 2; g++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
                 __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); /* nine VALU */
             }
@@ -1796,7 +1799,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
     /* fold the four chains of a lane: (a1 <= a2), (b1 <= b2) -> smallest two of the four */
     uint32_t f1[2], f2[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < MM_NU; u++) {
         f1[u] = k1[u][0];
         f2[u] = k2[u][0];
 #pragma unroll
@@ -1808,7 +1811,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(const uint32_t *__restric
     }
     /* lanes l and l + 32 hold the same query over different train rows */
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < MM_NU; u++) {
         const uint32_t o1 = (uint32_t)__shfl_xor((int)f1[u], 32, 64), o2 = (uint32_t)__shfl_xor((int)f2[u], 32, 64);
         uint32_t m1 = min(f1[u], o1), m2 = min(max(f1[u], o1), min(f2[u], o2));
         if (m1 >= 0x20000000u) m1 = 0xFFFFFFFFu; /* only excluded rows were seen */
