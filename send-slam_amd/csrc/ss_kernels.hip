@@ -1627,7 +1627,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #ifndef MM_NU
 #define MM_NU 1 /* 32-query B tiles per wave: 1 = 117 VGPRs, four waves per SIMD; 2 = 198 VGPRs, two (measured: 1 is as fast alone and 2 % faster with four batches in flight -- it leaves room next to the other kernels) */
 #endif
-#define MM_QBLOCK (128 * MM_NU)
+#ifndef MM_WAVES
+#define MM_WAVES 4 /* waves per block sharing the train tiles (8: -2.5 % frames/s with four batches in flight) */
+#endif
+#define MM_QBLOCK (32 * MM_NU * MM_WAVES)
 
 /* best / second best per lane, kept as FOUR independent (k1, k2) chains (register groups r >> 2) so the three
  * dependent instructions of one element overlap with those of its neighbours; the chains merge once, at the end */
@@ -1643,7 +1646,7 @@ __device__ __forceinline__ void mm_select(const v16i &acc, uint32_t kb0, uint32_
     }
 }
 
-__global__ __launch_bounds__(256, MM_NU == 2 ? 2 : 4) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
+__global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
                                                     const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                     int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                     int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
@@ -1671,13 +1674,14 @@ __global__ __launch_bounds__(256, MM_NU == 2 ? 2 : 4) void k_match_mfma(const ui
     /* byte -> eight +1 / -1 bytes (bit i of the byte -> byte i): spread the nibble's bits to byte lanes by one
      * multiplication, then 1 -> 0x01, 0 -> 0xFF */
     {
-        const uint32_t t = threadIdx.x;
+        const uint32_t t = threadIdx.x & 255u;
         const uint32_t lo = ((t & 15u) * 0x204081u) & 0x01010101u, hi = ((t >> 4) * 0x204081u) & 0x01010101u;
-        lut[t] = make_uint2(lo | ((lo ^ 0x01010101u) * 0xFFu), hi | ((hi ^ 0x01010101u) * 0xFFu));
+        if (threadIdx.x < 256) lut[t] = make_uint2(lo | ((lo ^ 0x01010101u) * 0xFFu), hi | ((hi ^ 0x01010101u) * 0xFFu));
     }
     /* the packed word of the first tile this thread will expand: row t >> 3 of the tile, word t & 7 */
-    const int erow = (int)(threadIdx.x >> 3), eword = (int)(threadIdx.x & 7);
-    uint32_t wnext = (n_tiles > 0 && c0 + erow < c1) ? tf[(size_t)(c0 + erow) * 8 + eword] : 0u;
+    const bool expander = MM_WAVES == 4 || threadIdx.x < 256; /* the first 256 threads expand the tiles */
+    const int erow = (int)((threadIdx.x & 255u) >> 3), eword = (int)(threadIdx.x & 7);
+    uint32_t wnext = (expander && n_tiles > 0 && c0 + erow < c1) ? tf[(size_t)(c0 + erow) * 8 + eword] : 0u;
     uint32_t qw[2][8];
 #pragma unroll
     for (int u = 0; u < MM_NU; u++) {
@@ -1700,6 +1704,7 @@ __global__ __launch_bounds__(256, MM_NU == 2 ? 2 : 4) void k_match_mfma(const ui
             bq[u][sstep] = v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
         }
     auto expand = [&](int buf, uint32_t w) {
+        if (!expander) return;
         w = ~w; /* the train side carries the minus sign */
         const uint2 e0 = lut[w & 0xFFu], e1 = lut[(w >> 8) & 0xFFu], e2 = lut[(w >> 16) & 0xFFu], e3 = lut[w >> 24];
         uint4 *dst = (uint4 *)&tiles[buf][erow * MM_ROW_BYTES + eword * 32];
@@ -1708,7 +1713,7 @@ __global__ __launch_bounds__(256, MM_NU == 2 ? 2 : 4) void k_match_mfma(const ui
     };
     auto load_word = [&](int tile) -> uint32_t {
         const int j = c0 + tile * MM_TILE + erow;
-        return (tile < n_tiles && j < c1) ? tf[(size_t)j * 8 + eword] : 0u;
+        return (expander && tile < n_tiles && j < c1) ? tf[(size_t)j * 8 + eword] : 0u;
     };
     const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
     const int q_lo = qbase, q_hi = qbase + 32 * MM_NU;
@@ -2089,7 +2094,7 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
     if (out_stride >= SSK_MATCH_MFMA_MIN_QUERIES) {
         /* many queries: the matrix-core form (256 queries per block) */
         dim3 grid((out_stride + MM_QBLOCK - 1) / MM_QBLOCK, n_chunks, n_frames);
-        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(64 * MM_WAVES), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
                            nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
                            n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
     } else {
