@@ -1624,13 +1624,13 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 #define MM_ROW_BYTES 272
 #define MM_TILE 32
-#ifndef MM_NU
-#define MM_NU 1 /* 32-query B tiles per wave: 1 = 117 VGPRs, four waves per SIMD; 2 = 198 VGPRs, two (measured: 1 is as fast alone and 2 % faster with four batches in flight -- it leaves room next to the other kernels) */
-#endif
+/* NU = 32-query B tiles per wave.  1: 117 VGPRs, four waves per SIMD -- as fast alone on the 2000 x 2000 frames and 2 % more
+ * frames/s with four batches in flight (it leaves room next to the other kernels).  2: 198 VGPRs, two waves per SIMD, half the
+ * LDS reads per MFMA -- 17 % faster on a large database that has the chip to itself (2000 x 20 M: 10.0 vs 11.7 ms). */
 #ifndef MM_WAVES
 #define MM_WAVES 4 /* waves per block sharing the train tiles (8: -2.5 % frames/s with four batches in flight) */
 #endif
-#define MM_QBLOCK (32 * MM_NU * MM_WAVES)
+#define MM_QBLOCK(NU) (32 * (NU) * MM_WAVES)
 
 /* best / second best per lane, kept as FOUR independent (k1, k2) chains (register groups r >> 2) so the three
  * dependent instructions of one element overlap with those of its neighbours; the chains merge once, at the end */
@@ -1646,7 +1646,8 @@ __device__ __forceinline__ void mm_select(const v16i &acc, uint32_t kb0, uint32_
     }
 }
 
-__global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
+template <int NU>
+__global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(const uint32_t *__restrict__ query, const uint32_t *__restrict__ train,
                                                     const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                     int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                     int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
@@ -1666,10 +1667,10 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
     const uint32_t *tf = train + (size_t)tframe * t_frame_stride;
     const int lane = lane_id(), col = lane & 31, half = lane >> 5;
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int qbase = blockIdx.x * MM_QBLOCK + wave * (32 * MM_NU); /* this wave's queries: MM_NU 32-column B tiles */
+    const int qbase = blockIdx.x * MM_QBLOCK(NU) + wave * (32 * NU); /* this wave's queries: NU 32-column B tiles */
     const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
     /* a block whose 256 query rows are all past the frame's count has nothing to select: no tiles */
-    const int n_tiles = (int)(blockIdx.x * MM_QBLOCK) < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
+    const int n_tiles = (int)(blockIdx.x * MM_QBLOCK(NU)) < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
 
     /* byte -> eight +1 / -1 bytes (bit i of the byte -> byte i): spread the nibble's bits to byte lanes by one
      * multiplication, then 1 -> 0x01, 0 -> 0xFF */
@@ -1684,7 +1685,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
     uint32_t wnext = (expander && n_tiles > 0 && c0 + erow < c1) ? tf[(size_t)(c0 + erow) * 8 + eword] : 0u;
     uint32_t qw[2][8];
 #pragma unroll
-    for (int u = 0; u < MM_NU; u++) {
+    for (int u = 0; u < NU; u++) {
         const int qi = qbase + 32 * u + col;
         const uint4 *p = (const uint4 *)(qf + (size_t)(qi < nq ? qi : 0) * 8);
         const uint4 a = p[0], b = p[1];
@@ -1696,7 +1697,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
      * same correspondence, which is all the contraction needs) */
     v4i bq[2][8];
 #pragma unroll
-    for (int u = 0; u < MM_NU; u++)
+    for (int u = 0; u < NU; u++)
 #pragma unroll
         for (int sstep = 0; sstep < 8; sstep++) {
             const uint32_t hw = (qw[u][sstep] >> (16 * half)) & 0xFFFFu;
@@ -1716,7 +1717,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
         return (expander && tile < n_tiles && j < c1) ? tf[(size_t)j * 8 + eword] : 0u;
     };
     const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
-    const int q_lo = qbase, q_hi = qbase + 32 * MM_NU;
+    const int q_lo = qbase, q_hi = qbase + 32 * NU;
     /* Rows that must not compete -- past the end of the chunk, or the query itself in a self-match -- enter through
      * the accumulator input: C = 2^15 there, which puts their keys above every real key (folded to "none" at the
      * end).  Only the tiles that contain such rows (wave-uniform test) build a C vector; all others start from the
@@ -1736,10 +1737,10 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
                 ci1[r] = (row >= rows_valid || row == skip1) ? 32768 : 0;
             }
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], ci0, 0, 0, 0);
-            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], ci1, 0, 0, 0);
+            if (NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], ci1, 0, 0, 0);
         } else {
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0][0], v16i{0}, 0, 0, 0);
-            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], v16i{0}, 0, 0, 0);
+            if (NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[1][0], v16i{0}, 0, 0, 0);
         }
     };
     auto mfma_rest = [&](int tile, v16i &acc0, v16i &acc1) {
@@ -1748,7 +1749,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
         for (int sstep = 1; sstep < 8; sstep++) {
             const v4i a = *(const v4i *)(arow + 32 * sstep);
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][sstep], acc0, 0, 0, 0);
-            if (MM_NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][sstep], acc1, 0, 0, 0);
+            if (NU > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][sstep], acc1, 0, 0, 0);
         }
     };
     uint32_t k1[2][4], k2[2][4];
@@ -1759,7 +1760,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
     auto select_tile = [&](int i, const v16i &acc0, const v16i &acc1) {
         const uint32_t kb0 = (256u << 15) + (uint32_t)(i * MM_TILE + 4 * half);
         mm_select(acc0, kb0, k1[0], k2[0]);
-        if (MM_NU > 1) mm_select(acc1, kb0, k1[1], k2[1]);
+        if (NU > 1) mm_select(acc1, kb0, k1[1], k2[1]);
     };
     /* software pipeline: the MFMAs of tile i + 1 and the selection from tile i's accumulators sit in one basic block,
      * interleaved (one MFMA, then the VALU that fits in its 32 cycles), while tile i + 2 is expanded into the buffer
@@ -1781,7 +1782,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
             mfma_rest(i + 1, nxt0, nxt1);
             select_tile(i, cur0, cur1);
 #pragma unroll
-            for (int g = 0; g < 8 * MM_NU - 2; g++) {
+            for (int g = 0; g < 8 * NU - 2; g++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
                 __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); /* nine VALU */
             }
@@ -1804,7 +1805,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
     /* fold the four chains of a lane: (a1 <= a2), (b1 <= b2) -> smallest two of the four */
     uint32_t f1[2], f2[2];
 #pragma unroll
-    for (int u = 0; u < MM_NU; u++) {
+    for (int u = 0; u < NU; u++) {
         f1[u] = k1[u][0];
         f2[u] = k2[u][0];
 #pragma unroll
@@ -1816,7 +1817,7 @@ __global__ __launch_bounds__(64 * MM_WAVES, MM_NU == 2 ? 2 : 4) void k_match_mfm
     }
     /* lanes l and l + 32 hold the same query over different train rows */
 #pragma unroll
-    for (int u = 0; u < MM_NU; u++) {
+    for (int u = 0; u < NU; u++) {
         const uint32_t o1 = (uint32_t)__shfl_xor((int)f1[u], 32, 64), o2 = (uint32_t)__shfl_xor((int)f2[u], 32, 64);
         uint32_t m1 = min(f1[u], o1), m2 = min(max(f1[u], o1), min(f2[u], o2));
         if (m1 >= 0x20000000u) m1 = 0xFFFFFFFFu; /* only excluded rows were seen */
@@ -2064,12 +2065,16 @@ void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, co
                        n_kp, kps, desc);
 }
 
+/* which form of the matrix-core kernel: a single large database has the chip to itself (NU = 2), batches of frames share it */
+static int mm_tiles_per_wave(int n_train_max, int n_frames) { return n_frames == 1 && n_train_max >= 65536 ? 2 : 1; }
+
 int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len)
 {
     /* the matrix-core kernel: 256 queries per block, 2 resident blocks per CU, and a per-block prologue (table, query
      * fragments) that wants >= 8 tiles of 32 train rows behind it; the VALU kernel: 64 queries per block, 8 per CU */
     const bool mfma = n_query_max >= SSK_MATCH_MFMA_MIN_QUERIES;
-    const int q_groups = mfma ? (n_query_max + MM_QBLOCK - 1) / MM_QBLOCK : (n_query_max + 63) / 64;
+    const int qblock = MM_QBLOCK(mm_tiles_per_wave(n_train_max, n_frames));
+    const int q_groups = mfma ? (n_query_max + qblock - 1) / qblock : (n_query_max + 63) / 64;
     const long blocks_wanted = mfma ? 2048 : 16384; /* >> resident blocks: keeps the last partial round of blocks small */
     long chunks = (blocks_wanted + (long)q_groups * n_frames - 1) / ((long)q_groups * n_frames > 0 ? (long)q_groups * n_frames : 1);
     const long max_chunks = (n_train_max + 255) / 256; /* >= 64 train rows per wave / >= 8 tiles per block */
@@ -2092,11 +2097,17 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
                int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames)
 {
     if (out_stride >= SSK_MATCH_MFMA_MIN_QUERIES) {
-        /* many queries: the matrix-core form (256 queries per block) */
-        dim3 grid((out_stride + MM_QBLOCK - 1) / MM_QBLOCK, n_chunks, n_frames);
-        hipLaunchKernelGGL(k_match_mfma, grid, dim3(64 * MM_WAVES), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
-                           nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
-                           n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+        /* many queries: the matrix-core form */
+        const int nu = mm_tiles_per_wave(nt_fixed, n_frames);
+        dim3 grid((out_stride + MM_QBLOCK(nu) - 1) / MM_QBLOCK(nu), n_chunks, n_frames);
+        if (nu == 2)
+            hipLaunchKernelGGL(k_match_mfma<2>, grid, dim3(64 * MM_WAVES), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr,
+                               nt_arr, nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
+                               n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
+        else
+            hipLaunchKernelGGL(k_match_mfma<1>, grid, dim3(64 * MM_WAVES), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr,
+                               nt_arr, nq_fixed, nt_fixed, q_frame_stride_words, t_frame_stride_words, train_frame_shift, chunk_len,
+                               n_chunks, exclude_self_mode, th, rnum, rden, out_stride, (match_partial *)partial, idx, d1, d2);
     } else {
         dim3 grid((out_stride + 63) / 64, n_chunks, n_frames);
         hipLaunchKernelGGL(k_match, grid, dim3(256), 0, s, (const uint32_t *)query, (const uint32_t *)train, nq_arr, nt_arr,
