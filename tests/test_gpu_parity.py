@@ -183,6 +183,30 @@ def test_match_ragged_sizes_vs_oracle(oracle, nq, nt):
                 assert np.array_equal(a, b)
 
 
+def test_match_random_sizes_vs_oracle(oracle):
+    # seeded sweep over both matcher kernels: sizes around every tiling boundary drawn at random, low-entropy descriptors
+    # (few distinct bytes) so that distance ties -- the lowest-index rule -- and d1 == d2 are everywhere, self-matches
+    rng = np.random.default_rng(4242)
+    with binding.OrbContext(0) as ctx:
+        for case in range(60):
+            nq = int(rng.choice([rng.integers(1, 128), rng.integers(128, 700), rng.choice([128, 160, 256, 384, 512])]))
+            nt = int(rng.choice([rng.integers(0, 70), rng.integers(70, 3000), rng.choice([32, 64, 96, 1024, 2048])]))
+            vals = rng.integers(0, 256, size=int(rng.integers(2, 6)), dtype=np.uint8)
+            lowent = case % 3 == 0
+            q = (vals[rng.integers(0, len(vals), size=(nq, 32))] if lowent else rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)).astype(np.uint8)
+            t = (vals[rng.integers(0, len(vals), size=(nt, 32))] if lowent else rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)).astype(np.uint8)
+            kw = dict(th=int(rng.choice([50, 100, 256])), ratio_num=int(rng.choice([7, 9, 10])), ratio_den=10)
+            got = ctx.match(q, t, **kw)
+            want = oracle.match(q, t, **kw)
+            for a, b, name in zip(got, want, ("idx", "d1", "d2")):
+                assert np.array_equal(a, b), f"case {case}: {name} differs (nq={nq}, nt={nt}, {kw})"
+            if case % 2 == 0:
+                got = ctx.match(q, q, exclude_self=True, **kw)
+                want = oracle.match(q, q, exclude_self=True, **kw)
+                for a, b, name in zip(got, want, ("idx", "d1", "d2")):
+                    assert np.array_equal(a, b), f"case {case}: self-match {name} differs (nq={nq}, {kw})"
+
+
 def test_match_large_database_chunked(oracle):
     # loop-closure shape (config 5 of BASELINE.json, scaled down): many train chunks, ties across chunks
     rng = np.random.default_rng(77)
