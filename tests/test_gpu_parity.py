@@ -207,6 +207,29 @@ def test_match_random_sizes_vs_oracle(oracle):
                     assert np.array_equal(a, b), f"case {case}: self-match {name} differs (nq={nq}, {kw})"
 
 
+def test_match_self_exclusion_in_the_large_database_form():
+    # the two-tiles-per-wave form of the matrix-core kernel (one frame, >= 65 536 train rows) with j == i excluded: a
+    # 66 000-row self-match, checked for a sample of queries against distances computed here with numpy (the oracle's
+    # exclusion is by query index, so it cannot check a subset)
+    rng = np.random.default_rng(99)
+    n = 66_000
+    q = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    q[40_000] = q[5]            # an exact copy far away: d1 == 0 for both
+    q[65_999] = q[65_536]
+    q[65_998] = q[65_536]       # two copies: tie, lowest index wins
+    sel = [0, 5, 31, 32, 63, 64, 127, 128, 255, 256, 40_000, 65_535, 65_536, 65_998, 65_999]
+    with binding.OrbContext(0) as ctx:
+        idx, d1, d2 = ctx.match(q, q, th=-1, ratio_num=10, exclude_self=True)  # raw mode: best row, no acceptance test
+    popc = np.unpackbits(np.arange(256, dtype=np.uint8)[:, None], axis=1).sum(1).astype(np.int32)
+    for i in sel:
+        d = popc[q ^ q[i]].sum(1)
+        d[i] = 1 << 20
+        j = int(np.argmin(d))  # first minimum = lowest index
+        rest = np.delete(d, j)
+        assert (int(idx[i]), int(d1[i]), int(d2[i])) == (j, int(d[j]), int(rest.min())), i
+    assert d1[5] == 0 and idx[5] == 40_000 and idx[40_000] == 5 and idx[65_536] == 65_998 and d2[65_536] == 0
+
+
 def test_match_large_database_chunked(oracle):
     # loop-closure shape (config 5 of BASELINE.json, scaled down): many train chunks, ties across chunks
     rng = np.random.default_rng(77)
