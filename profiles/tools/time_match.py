@@ -1,6 +1,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, "send-slam_amd")
 from send_slam_amd import binding, synth
+if os.environ.get("SENDSLAM_LIB"): binding.LIB_PATH = os.environ["SENDSLAM_LIB"]
 B, n = 64, 2000
 w, h = 1280, 720
 ctx = binding.OrbContext(0, n_features=n, max_batch=B)
@@ -17,4 +18,4 @@ except Exception: pass
 for _ in range(20): ctx.match_batch_device(0, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
 ctx.synchronize()
 for s in ctx.stats():
-    if s["launches"] and "match" in s["name"]: print(os.environ.get("SSK_MFMA_BLOCKS"), s["name"], round(s["total_ms"] / 20, 4), s["launches"])
+    if s["launches"] and "match" in s["name"]: print(os.path.basename(os.environ.get("SENDSLAM_LIB", "default")), s["name"], round(s["total_ms"] / 20, 4), s["launches"])

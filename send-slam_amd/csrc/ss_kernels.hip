@@ -1781,11 +1781,16 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
             mfma_tile(i + 1, nxt0, nxt1);
             mfma_rest(i + 1, nxt0, nxt1);
             select_tile(i, cur0, cur1);
+#ifndef MM_SCHED_VALU
+#define MM_SCHED_VALU 9
+#endif
+#if MM_SCHED_VALU > 0
 #pragma unroll
             for (int g = 0; g < 8 * NU - 2; g++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */
-                __builtin_amdgcn_sched_group_barrier(0x002, 9, 0); /* nine VALU */
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             /* one MFMA */
+                __builtin_amdgcn_sched_group_barrier(0x002, MM_SCHED_VALU, 0); /* nine VALU */
             }
+#endif
         }
         if (i + 2 < n_tiles) expand(i & 1, wnext);
         wnext = load_word(i + 3);
