@@ -292,10 +292,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += FT_THREADS) (&out_tile[0][0])[i] = 0;
-    if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = x0 + (int)threadIdx.x < w ? cinfo[xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
+    /* window info of the tile's columns / rows: requested now, stored to LDS after the staging loads have been issued,
+     * so that the block waits for the two kinds of loads once, not one after the other */
+    uint16_t cinf_v = 0;
+    if (threadIdx.x < SS_TILE_W) cinf_v = x0 + (int)threadIdx.x < w ? cinfo[xinfo_off + x0 + threadIdx.x] : (uint16_t)0;
     else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) {
         const int k = (int)threadIdx.x - SS_TILE_W;
-        yinf[k] = y0 + k < h ? cinfo[yinfo_off + y0 + k] : (uint16_t)0;
+        cinf_v = y0 + k < h ? cinfo[yinfo_off + y0 + k] : (uint16_t)0;
     }
     /* stage rows y0-4 .. y0+35, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
      * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
@@ -336,6 +339,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             }
         }
     }
+    if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = cinf_v;
+    else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) yinf[threadIdx.x - SS_TILE_W] = cinf_v;
     __syncthreads();
 
     /* Phase 1, every pixel: the compass test of cv::FAST.  Any 9 contiguous ring pixels contain
