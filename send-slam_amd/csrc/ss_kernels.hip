@@ -1617,7 +1617,7 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
 /* one instruction, so the 16 XOR + popcount VALU per pair of k_match (profiles/r01_valu_rates.json: */
 /* v_bcnt issues at half rate) move to the otherwise idle MFMA pipe and the VALU keeps only the     */
 /* three instructions per pair that select best / second best.                                       */
-/* Block = 4 waves x 64 queries.  Queries are the B operand (column = lane & 31, resident in       */
+/* Block = 4 waves x NU x 32 queries.  Queries are the B operand (column = lane & 31, resident in */
 /* registers for the whole chunk), 32-row train tiles the A operand (expanded once per block into   */
 /* LDS through a 256-entry byte -> 8-byte table, rows padded to 272 B so ds_read_b128 is conflict   */
 /* free).  C/D layout: lane holds column (query) lane & 31 and train rows (r & 3) + 8 (r >> 2) +      */
