@@ -186,9 +186,9 @@ def test_match_ragged_sizes_vs_oracle(oracle, nq, nt):
 def test_match_random_sizes_vs_oracle(oracle):
     # seeded sweep over both matcher kernels: sizes around every tiling boundary drawn at random, low-entropy descriptors
     # (few distinct bytes) so that distance ties -- the lowest-index rule -- and d1 == d2 are everywhere, self-matches
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(int(os.environ.get("SENDSLAM_SOAK_SEED", 4242)))
     with binding.OrbContext(0) as ctx:
-        for case in range(60):
+        for case in range(int(os.environ.get("SENDSLAM_SOAK_CASES", 60))):
             nq = int(rng.choice([rng.integers(1, 128), rng.integers(128, 700), rng.choice([128, 160, 256, 384, 512])]))
             nt = int(rng.choice([rng.integers(0, 70), rng.integers(70, 3000), rng.choice([32, 64, 96, 1024, 2048])]))
             vals = rng.integers(0, 256, size=int(rng.integers(2, 6)), dtype=np.uint8)
@@ -340,9 +340,10 @@ def test_random_geometries_and_contents_vs_oracle(oracle):
     """Seeded sweep over image sizes, feature counts, level counts, scale factors and contents (textured,
     half flat, low contrast, noise): every tile / cell-window / bucket geometry the kernels index blindly is
     exercised against the oracle, bit for bit."""
-    rng = np.random.default_rng(20261004)
+    # SENDSLAM_SOAK_CASES / SENDSLAM_SOAK_SEED: a longer run of the same sweep with other draws (by hand, on a GPU box)
+    rng = np.random.default_rng(int(os.environ.get("SENDSLAM_SOAK_SEED", 20261004)))
     checked = 0
-    for case in range(28):
+    for case in range(int(os.environ.get("SENDSLAM_SOAK_CASES", 28))):
         w, h = int(rng.integers(200, 900)), int(rng.integers(170, 700))
         nl = int(rng.integers(2, 9))
         scale = float(rng.choice([1.2, 1.25, 1.5]))
