@@ -17,6 +17,14 @@
  *   ss_extract_batch_device    same, for a batch of frames already resident in HBM (cameras /
  *                              frame batches shard one per GPU; no counterpart in the reference,
  *                              which handles one camera on one thread :594)
+ *   ss_pipe_*                  the same frame branch :521-627 for a STREAM of host frames: pinned ring,
+ *                              H2D copy / kernels / D2H copy of different batches overlapped, results in
+ *                              host memory -- what the copy at :325 + imdecode :546 + TrackMonocular :594
+ *                              do one frame at a time; host half slam_handler.ex:59-88
+ *   ss_track_features          the pose half of TrackMonocular :594 for a frame whose features a pipe
+ *                              extracted (front door read-ahead of queued frames)
+ *   ss_match_partial_device /  the local and the cross-shard half of a query against a database
+ *   ss_match_fold_device       partitioned over GPUs
  *   ss_match*                  ORBmatcher::DescriptorDistance + best/second-best search inside
  *                              TrackMonocular :594 (all-pairs rule: SURVEY.md Appendix A.6)
  *   ss_track                   TrackMonocular :594 -> Twc, tracking state :596 (bounded monocular
@@ -42,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 2
+#define SS_ABI_VERSION 3
 #define SS_MAX_LEVELS 16
 #define SS_DESC_BYTES 32
 
@@ -56,7 +64,8 @@ typedef enum {
     SS_ERR_NOT_CALIBRATED = -6, /* frame before calibration (shim :523-527) */
     SS_ERR_BAD_FRAME = -7,
     SS_ERR_NO_MEMORY = -8,
-    SS_ERR_STATE = -9
+    SS_ERR_STATE = -9,
+    SS_ERR_BUSY = -10 /* ss_pipe_acquire: every slot of the ring is in flight or not yet released */
 } ss_status;
 
 typedef struct ss_ctx ss_ctx;
@@ -73,6 +82,12 @@ typedef struct {
     int32_t lapping_x0;
     int32_t lapping_x1;
     int32_t max_batch; /* frames per ss_extract_batch_device call; >= 1 */
+    /* How the rotated rBRIEF tap coordinates cvRound(x*b + y*a), cvRound(x*a - y*b) of computeOrbDescriptor are
+     * evaluated.  0 (default): as written, every product and the sum rounded.  1: the first product fused into the
+     * sum, fma(x, b, y*a) / fma(x, a, -(y*b)) -- what GCC's FMA contraction makes of the expression when upstream is
+     * built -O3 -march=native (slam_backends/orb_slam_3/CMakeLists.txt:10-13) on an FMA-capable host.  Which one the
+     * reference binary runs is unpinned (tests/golden/ref_dump/README.md); a few descriptor bits per frame depend on it. */
+    int32_t steer_fma;
 } ss_orb_params;
 
 /* The 16 calibration scalars of the wire protocol (shim :59-77; produced by
@@ -114,6 +129,7 @@ typedef struct {
     const uint8_t *descriptors;    /* device: [n_frames][kp_capacity][32] */
     const int32_t *n_keypoints;    /* device: [n_frames] */
     const int32_t *level_counts;   /* device: [n_frames][SS_MAX_LEVELS] */
+    const int32_t *frame_error;    /* device: [n_frames]; 0 or the ss_status of a frame whose capacity was exceeded */
 } ss_batch_view;
 
 typedef struct {
@@ -194,7 +210,34 @@ int ss_track(ss_ctx *ctx, int camera_id, const uint8_t *pix, int width, int heig
 /* back to NO_IMAGES_YET (System::Reset / the "terminate" message :462-469) */
 int ss_track_reset(ss_ctx *ctx);
 
+/* Pose step alone (ss_track without its ss_extract): the frame's descriptors are n rows of 32 bytes in DEVICE memory
+ * (e.g. ss_pipe_result.d_descriptors of a completed slot), its keypoints are host memory.  Same state machine, same
+ * match (th 50, ratio 0.9) and geometry as ss_track; frames must arrive in camera order. */
+int ss_track_features(ss_ctx *ctx, int camera_id, double timestamp, const void *d_descriptors,
+                      const ss_keypoint *keypoints, int n_keypoints, ss_pose *out);
+
+/* ---- a database partitioned over GPUs ------------------------------------
+ * A shard reports, per query descriptor, ss_match_part = (best distance, second-best distance, GLOBAL row of the
+ * best or -1): 8 bytes, the unit every rank all-gathers.  ss_match_partial_device runs the raw local match of
+ * n_query device descriptors against this shard's n_train rows (global row = row_offset + local row) and writes
+ * d_part[n_query].  ss_match_fold_device folds n_parts such arrays laid out [part][n_query], parts in ASCENDING
+ * row order, with the rule the match kernels use across their train chunks (ties keep the lower row; second best =
+ * min over the losers' best and everyone's second best), then applies the acceptance test of ss_match.  One
+ * launch; asynchronous on the context's stream. */
+typedef struct {
+    uint16_t d1, d2; /* 0xFFFF = none */
+    int32_t row;     /* global row of the best, -1 = none */
+} ss_match_part;
+int ss_match_partial_device(ss_ctx *ctx, const void *d_query, int n_query, const void *d_train, int n_train,
+                            int64_t row_offset, void *d_part);
+int ss_match_fold_device(ss_ctx *ctx, const void *d_parts, int n_parts, int n_query, int th, int ratio_num,
+                         int ratio_den, void *d_idx, void *d_d1, void *d_d2);
+
 int ss_synchronize(ss_ctx *ctx);
+/* Orders the context's stream after everything enqueued so far on another stream of the same device
+ * (hipStream_t; NULL = the legacy default stream): for callers that produce the inputs of a *_device call on their own
+ * stream (a collective's output, a decoder) and must not launch the match before they are written. */
+int ss_wait_stream(ss_ctx *ctx, void *hip_stream);
 /* the hipStream_t every kernel of this context is launched on */
 int ss_get_stream(ss_ctx *ctx, void **hip_stream);
 
@@ -216,6 +259,73 @@ int ss_debug_fetch(ss_ctx *ctx, int what, int frame, int level, void *dst, int64
  * std::sort for ORB-SLAM3's compareNodes.  Item = size << 32 | UL.x << 20 | id (20 bits); the
  * comparator looks at (size, UL.x) only, so the placement of equal keys is what is tested. */
 int ss_debug_sort(ss_ctx *ctx, uint64_t *items, int n);
+
+/* ---- pipelined host-memory path ----------------------------------------------------------------------------
+ * A pipe owns a ring of `depth` slots.  A slot = pinned host memory for `batch` frames + its own extraction
+ * context (HBM buffers, HIP stream) + pinned host memory for the results.  Producer side: ss_pipe_acquire hands out
+ * a free slot, the caller decodes / receives / copies frames straight into slot.pixels (frame i at
+ * pixels + i * frame_stride, rows of row_stride bytes) and calls ss_pipe_submit; or ss_pipe_submit_frames gathers
+ * caller-owned frames into a slot with a few host threads and submits it.  Submission enqueues, on the slot's stream,
+ * H2D copy -> extraction (-> match) -> D2H copy of the results and returns at once, so the copies of one batch overlap
+ * the kernels of the others.  Consumer side: ss_pipe_wait / ss_pipe_poll return completed batches in submission
+ * order; the result arrays are the slot's pinned host memory and stay valid until ss_pipe_release(slot), which puts
+ * the slot back into the ring.  A frame that is bad (NULL pointer, camera id 0) or exceeds an internal capacity gets
+ * its own status; the other frames of the batch are unaffected (the shim's log-and-skip policy :523-551).
+ * One producer thread and one consumer thread (or one thread doing both) per pipe. */
+typedef struct ss_pipe ss_pipe;
+
+typedef struct {
+    int32_t width, height, channels; /* every frame of the pipe has this shape */
+    int32_t batch;                   /* frames per slot, 1..256 */
+    int32_t depth;                   /* slots, 2..16 */
+    int32_t match_mode;              /* -1 none; 0 self-match; 1 frame b against frame b-1 of the batch (ss_match_batch_device) */
+    int32_t match_th, ratio_num, ratio_den; /* 0 0 0 = the defaults 50, 9, 10 */
+    int32_t copy_threads;            /* host threads of ss_pipe_submit_frames; 0 = 4 */
+} ss_pipe_config;
+
+typedef struct {
+    int32_t slot;
+    uint8_t *pixels; /* pinned host memory, batch * frame_stride bytes */
+    int64_t row_stride, frame_stride;
+} ss_pipe_slot;
+
+typedef struct {
+    int32_t slot;
+    int32_t n_frames;
+    int32_t kp_capacity;          /* rows per frame in the per-keypoint arrays */
+    uint64_t sequence;            /* 0, 1, 2 ... in submission order */
+    const int32_t *status;        /* [n_frames] SS_OK or the frame's ss_status */
+    const int32_t *camera_id;     /* [n_frames] as submitted */
+    const double *timestamp;      /* [n_frames] as submitted */
+    const int32_t *n_keypoints;   /* [n_frames]; 0 for a frame whose status is not SS_OK */
+    const int32_t *level_counts;  /* [n_frames][SS_MAX_LEVELS] */
+    const ss_keypoint *keypoints; /* [n_frames][kp_capacity] */
+    const uint8_t *descriptors;   /* [n_frames][kp_capacity][32] */
+    const int32_t *match_idx;     /* [n_frames][kp_capacity], NULL when match_mode < 0 */
+    const uint16_t *match_d1, *match_d2;
+    const void *d_descriptors;    /* DEVICE copy of `descriptors` (same layout), valid until ss_pipe_release */
+} ss_pipe_result;
+
+/* cam may be NULL for 1-channel frames (its rgb flag decides the gray weights of 3/4-channel frames) */
+int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_camera *cam,
+                   const ss_pipe_config *cfg, ss_pipe **out);
+int ss_pipe_destroy(ss_pipe *pipe);
+/* pipe may be NULL: message of the last failed ss_pipe_create on this thread */
+const char *ss_pipe_last_error(const ss_pipe *pipe);
+int ss_pipe_acquire(ss_pipe *pipe, ss_pipe_slot *out);
+/* camera_ids / timestamps: n_frames entries each, or NULL (camera 1, timestamp 0) */
+int ss_pipe_submit(ss_pipe *pipe, int slot, int n_frames, const int32_t *camera_ids, const double *timestamps);
+/* frames[i]: caller-owned host image of the pipe's shape with rows of row_stride bytes (NULL = a bad frame);
+ * consumed before the call returns.  SS_ERR_BUSY when no slot is free. */
+int ss_pipe_submit_frames(ss_pipe *pipe, const uint8_t *const *frames, int n_frames, int64_t row_stride,
+                          const int32_t *camera_ids, const double *timestamps);
+/* oldest submitted batch: wait blocks until it has completed; poll returns 1 (completed, *out filled), 0 (still
+ * running, or nothing submitted) or < 0 */
+int ss_pipe_wait(ss_pipe *pipe, ss_pipe_result *out);
+int ss_pipe_poll(ss_pipe *pipe, ss_pipe_result *out);
+int ss_pipe_release(ss_pipe *pipe, int slot);
+/* batches submitted and not yet returned by wait / poll */
+int ss_pipe_in_flight(const ss_pipe *pipe);
 
 #ifdef __cplusplus
 }

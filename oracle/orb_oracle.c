@@ -44,6 +44,7 @@ void orc_default_params(orc_params *p)
     p->min_th_fast = ORC_DEFAULT_MIN_TH;
     p->lapping_x0 = ORC_DEFAULT_LAPPING_X0;
     p->lapping_x1 = ORC_DEFAULT_LAPPING_X1;
+    p->steer_fma = 0;
 }
 
 /* ORBextractor::ORBextractor: scale tables, per-level quotas, umax */
@@ -749,8 +750,22 @@ void orc_blur(const uint8_t *src, int w, int h, uint8_t *dst)
 /* ---- K6b: computeOrbDescriptor ------------------------------------------------------ */
 static const int k_pattern[1024] = ORC_BIT_PATTERN_31;
 
-void orc_descriptor(const uint8_t *img, int pitch, int x, int y, float angle_deg,
-                    uint8_t desc[32])
+static int tap_row(int px, int py, float a, float b, int fma)
+{
+    return cv_round_f(fma ? fmaf((float)px, b, (float)py * a) : (float)px * b + (float)py * a);
+}
+static int tap_col(int px, int py, float a, float b, int fma)
+{
+    return cv_round_f(fma ? fmaf((float)px, a, -((float)py * b)) : (float)px * a - (float)py * b);
+}
+
+void orc_descriptor(const uint8_t *img, int pitch, int x, int y, float angle_deg, uint8_t desc[32])
+{
+    orc_descriptor_ex(img, pitch, x, y, angle_deg, 0, desc);
+}
+
+void orc_descriptor_ex(const uint8_t *img, int pitch, int x, int y, float angle_deg, int steer_fma,
+                       uint8_t desc[32])
 {
     const float factor_pi = (float)(3.14159265358979323846 / 180.f);
     const float angle = angle_deg * factor_pi;
@@ -768,8 +783,8 @@ void orc_descriptor(const uint8_t *img, int pitch, int x, int y, float angle_deg
         for (int bit = 0; bit < 8; bit++) {
             const int x0 = pat[4 * bit], y0 = pat[4 * bit + 1];
             const int x1 = pat[4 * bit + 2], y1 = pat[4 * bit + 3];
-            const int t0 = center[cv_round_f(x0 * b + y0 * a) * pitch + cv_round_f(x0 * a - y0 * b)];
-            const int t1 = center[cv_round_f(x1 * b + y1 * a) * pitch + cv_round_f(x1 * a - y1 * b)];
+            const int t0 = center[tap_row(x0, y0, a, b, steer_fma) * pitch + tap_col(x0, y0, a, b, steer_fma)];
+            const int t1 = center[tap_row(x1, y1, a, b, steer_fma) * pitch + tap_col(x1, y1, a, b, steer_fma)];
             val |= (t0 < t1) << bit;
         }
         desc[i] = (uint8_t)val;
@@ -836,7 +851,7 @@ int orc_extract(const uint8_t *gray, int w, int h, int stride, const orc_params 
                 kp.angle = lvl_ang[l][i];
                 kp.response = (float)lvl_pts[l][i].response;
                 uint8_t d[32];
-                orc_descriptor(blurred, g.w[l], lvl_pts[l][i].x, lvl_pts[l][i].y, kp.angle, d);
+                orc_descriptor_ex(blurred, g.w[l], lvl_pts[l][i].x, lvl_pts[l][i].y, kp.angle, p->steer_fma, d);
                 if (l != 0) { kp.x *= scale; kp.y *= scale; }
                 int slot;
                 if (kp.x >= (float)p->lapping_x0 && kp.x <= (float)p->lapping_x1) slot = stereo--;

@@ -37,6 +37,10 @@ typedef struct {
     int min_th_fast;
     int lapping_x0; /* ORB-SLAM3 vLappingArea; mono default {0, 1000} */
     int lapping_x1;
+    /* rBRIEF tap coordinates: 0 = x*b + y*a with every operation rounded (the expression as written); 1 = the
+     * first product fused, fmaf(x, b, y*a) / fmaf(x, a, -(y*b)): GCC's contraction of the same expression under
+     * upstream's -O3 -march=native (CMakeLists.txt:10-13).  Which one the reference binary runs is unpinned. */
+    int steer_fma;
 } orc_params;
 
 typedef struct {
@@ -106,6 +110,9 @@ float orc_ic_angle(const uint8_t *img, int pitch, int x, int y, const int *umax)
 void orc_blur(const uint8_t *src, int w, int h, uint8_t *dst);
 void orc_descriptor(const uint8_t *blurred, int pitch, int x, int y, float angle_deg,
                     uint8_t desc[32]);
+/* steer_fma: see orc_params */
+void orc_descriptor_ex(const uint8_t *blurred, int pitch, int x, int y, float angle_deg, int steer_fma,
+                       uint8_t desc[32]);
 
 /* full extractor; returns number of keypoints (<= max_kp) or <0 on error.
  * level_counts (optional, n_levels ints) receives per-level keypoint counts. */

@@ -19,7 +19,7 @@ MAX_LEVELS = 16
 class Params(C.Structure):
     _fields_ = [("n_features", C.c_int), ("scale_factor", C.c_float), ("n_levels", C.c_int),
                 ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int),
-                ("lapping_x0", C.c_int), ("lapping_x1", C.c_int)]
+                ("lapping_x0", C.c_int), ("lapping_x1", C.c_int), ("steer_fma", C.c_int)]
 
 
 class Keypoint(C.Structure):
@@ -158,11 +158,11 @@ def blur(img: np.ndarray) -> np.ndarray:
     return out
 
 
-def descriptor(blurred: np.ndarray, x: int, y: int, angle_deg: float) -> np.ndarray:
+def descriptor(blurred: np.ndarray, x: int, y: int, angle_deg: float, steer_fma: int = 0) -> np.ndarray:
     blurred = np.ascontiguousarray(blurred)
     out = np.empty(32, np.uint8)
-    lib().orc_descriptor(_u8p(blurred), blurred.shape[1], int(x), int(y), C.c_float(angle_deg),
-                         _u8p(out))
+    lib().orc_descriptor_ex(_u8p(blurred), blurred.shape[1], int(x), int(y), C.c_float(angle_deg), int(steer_fma),
+                            _u8p(out))
     return out
 
 

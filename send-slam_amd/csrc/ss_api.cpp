@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ struct ss_ctx {
     ss_orb_params params{};
     std::string err;
     bool calibrated = false;
+    bool force_ingest = false; /* SENDSLAM_FORCE_INGEST=1: always copy level 0 into the pyramid block (tests) */
     ss_camera cam{};
     int cam_id = 0;
 
@@ -77,8 +79,8 @@ struct ss_ctx {
     size_t d_in_bytes = 0;
     void *match_partial = nullptr;
     size_t match_partial_bytes = 0;
-    uint8_t *d_mq = nullptr, *d_mt = nullptr, *d_mout = nullptr;
-    size_t d_mq_bytes = 0, d_mt_bytes = 0, d_mout_bytes = 0;
+    uint8_t *d_mq = nullptr, *d_mt = nullptr, *d_mout = nullptr, *d_part_tmp = nullptr;
+    size_t d_mq_bytes = 0, d_mt_bytes = 0, d_mout_bytes = 0, d_part_tmp_bytes = 0;
 
     /* host results of ss_extract */
     std::vector<ss_keypoint> h_kps;
@@ -86,6 +88,7 @@ struct ss_ctx {
     std::vector<int32_t> h_err;
 
     int last_n_frames = 0;
+    ss_lvl0 last_lvl0; /* where level 0 of the last batch lives (ptr == NULL: in the pyramid block) */
 
     /* ss_track: descriptors of the initialisation reference / the previous frame, host geometry */
     uint8_t *d_ref_desc = nullptr, *d_prev_desc = nullptr;
@@ -268,7 +271,18 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     for (int l = 0; l < g.n_levels; l++) all_px += level_px(g, l);
 
     HIP_TRY(c, hipMemsetAsync(c->state, 0, (size_t)n * SS_MAX_LEVELS * sizeof(ss_level_state), s));
-    {
+    /* A 1-channel image whose base, rows and frames are 16-byte aligned IS pyramid level 0: the kernels read it in
+     * place (aligned dword loads work on it as they do on the pyramid block) and the ingest copy is skipped.  The
+     * caller's buffer must stay untouched until the batch has finished (it is asynchronous, as before). */
+    ss_lvl0 l0;
+    if (channels == 1 && ((uintptr_t)d_pix % 16) == 0 && row_stride % 16 == 0 && frame_stride % 16 == 0 &&
+        row_stride < (1 << 24) && !c->force_ingest) {
+        l0.ptr = (const uint8_t *)d_pix;
+        l0.pitch = (int)row_stride;
+        l0.frame_stride = frame_stride;
+    }
+    c->last_lvl0 = l0;
+    if (!l0.ptr) {
         int c0 = 0, c1 = 0, c2 = 0;
         if (channels != 1) { /* Camera.RGB: 1 -> byte 0 weighs as R */
             const bool rgb = c->calibrated ? c->cam.rgb != 0 : false;
@@ -281,13 +295,13 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     for (int l = 1; l < g.n_levels; l++) {
         stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
-        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n);
+        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n, l0);
     }
     {
         /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map and the
          * survivor lists are this design's own intermediates) */
         stage_timer t(c, "fast_blur_nms", n * 2 * all_px);
-        ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv, c->thdr, c->state, n);
+        ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv, c->thdr, c->state, n, l0);
     }
     {
         stage_timer t(c, "bucket_gather", 0);
@@ -307,7 +321,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     {
         stage_timer t(c, "orient_describe", (int64_t)n * g.n_features * (709 + 512 + 32 + 24));
-        ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n);
+        ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n, l0, c->params.steer_fma != 0);
     }
     HIP_TRY(c, hipGetLastError());
     c->last_n_frames = n;
@@ -356,6 +370,7 @@ int ss_orb_params_default(ss_orb_params *p)
     p->lapping_x0 = SS_DEFAULT_LAPPING_X0;
     p->lapping_x1 = SS_DEFAULT_LAPPING_X1;
     p->max_batch = 1;
+    p->steer_fma = 0;
     return SS_OK;
 }
 
@@ -386,6 +401,7 @@ int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
     ss_ctx *c = new ss_ctx();
     c->device = device_ordinal;
     c->params = p;
+    if (const char *e = getenv("SENDSLAM_FORCE_INGEST")) c->force_ingest = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
@@ -408,6 +424,7 @@ int ss_destroy(ss_ctx *c)
     dev_free(c->d_mq);
     dev_free(c->d_mt);
     dev_free(c->d_mout);
+    dev_free(c->d_part_tmp);
     dev_free(c->d_ref_desc);
     dev_free(c->d_prev_desc);
     (void)hipStreamDestroy(c->stream);
@@ -426,6 +443,9 @@ int ss_set_calibration(ss_ctx *c, int camera_id, const ss_camera *cam)
     c->cam.type[sizeof(c->cam.type) - 1] = 0;
     c->cam_id = camera_id;
     c->calibrated = true;
+    /* the reference rebuilds the whole ORB_SLAM3::System on every calibration message (:491-518): the map, the
+     * reference frame and the motion model do not survive it */
+    c->tracker.reset();
     return SS_OK;
 }
 
@@ -442,12 +462,14 @@ int ss_extract(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int heig
     if (row_stride < width * channels) return fail(c, SS_ERR_BAD_FRAME, "row_stride smaller than a row");
     int rc = ensure_geometry(c, width, height);
     if (rc != SS_OK) return rc;
-    const size_t bytes = (size_t)row_stride * height;
-    rc = grow(c, c->d_in, c->d_in_bytes, bytes);
+    /* the last row of a tight caller buffer ends after width * channels bytes, not after row_stride */
+    const size_t bytes = (size_t)row_stride * (height - 1) + (size_t)width * channels;
+    const size_t alloc = ((size_t)row_stride * height + 15) & ~(size_t)15;
+    rc = grow(c, c->d_in, c->d_in_bytes, alloc);
     if (rc != SS_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->d_in, pix, bytes, hipMemcpyHostToDevice, c->stream));
     /* the caller keeps ownership of pix: it is consumed before we return */
-    rc = run_extract(c, c->d_in, 1, channels, row_stride, (int64_t)bytes);
+    rc = run_extract(c, c->d_in, 1, channels, row_stride, (int64_t)alloc);
     if (rc != SS_OK) return rc;
     int32_t nk = 0;
     HIP_TRY(c, hipMemcpyAsync(&nk, c->n_kp, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -496,6 +518,7 @@ int ss_get_batch_view(ss_ctx *c, ss_batch_view *out)
     out->descriptors = c->desc;
     out->n_keypoints = c->n_kp;
     out->level_counts = c->level_counts;
+    out->frame_error = c->frame_error;
     return SS_OK;
 }
 
@@ -608,15 +631,11 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
     return SS_OK;
 }
 
-int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height, int channels, int row_stride,
-             double timestamp, ss_pose *out)
+/* the pose half of the frame branch: device match against the initial / previous frame's descriptors, then the host
+ * geometry (csrc/ss_track.cpp).  d_desc: n rows of 32 bytes in device memory, written on c->stream or complete. */
+static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t *d_desc, const ss_keypoint *kps, int n,
+                      ss_pose *out)
 {
-    if (!c || !out) return SS_ERR_INVALID_ARG;
-    if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
-    ss_frame_result res;
-    int rc = ss_extract(c, camera_id, pix, width, height, channels, row_stride, timestamp, &res);
-    if (rc != SS_OK) return rc;
-    const int n = res.n_keypoints;
     sst_tracker &tr = c->tracker;
     tr.cam = sst_camera{c->cam.fx, c->cam.fy, c->cam.cx, c->cam.cy, c->cam.k1, c->cam.k2, c->cam.p1, c->cam.p2};
     tr.scale_factor = c->params.scale_factor;
@@ -625,19 +644,19 @@ int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height
     c->h_midx.assign((size_t)std::max(n, 1), -1);
     c->h_md1.assign((size_t)std::max(n, 1), 0xFFFF);
     for (int i = 0; i < n; i++) {
-        c->h_xy[2 * i] = res.keypoints[i].x;
-        c->h_xy[2 * i + 1] = res.keypoints[i].y;
-        c->h_oct[i] = res.keypoints[i].octave;
+        c->h_xy[2 * i] = kps[i].x;
+        c->h_xy[2 * i + 1] = kps[i].y;
+        c->h_oct[i] = kps[i].octave;
     }
+    int rc;
     const int want = tr.want_match();
     if (want != SST_MATCH_NONE && n > 0) {
-        /* this frame's descriptors are still in HBM (frame 0 of the batch arrays) */
         const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : c->d_prev_desc;
         rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n * 8);
         if (rc != SS_OK) return rc;
         int32_t *di = (int32_t *)c->d_mout;
         uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
-        rc = ss_match_device(c, c->desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+        rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
         if (rc != SS_OK) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_midx.data(), di, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_md1.data(), dd1, (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
@@ -650,7 +669,7 @@ int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height
         size_t &dst_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_bytes : c->d_prev_desc_bytes;
         rc = grow(c, dst, dst_bytes, (size_t)n * SS_DESC_BYTES);
         if (rc != SS_OK) return rc;
-        HIP_TRY(c, hipMemcpyAsync(dst, c->desc, (size_t)n * SS_DESC_BYTES, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dst, d_desc, (size_t)n * SS_DESC_BYTES, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     out->tracking_state = po.state;
@@ -662,6 +681,76 @@ int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height
     out->n_matches = po.n_matches;
     out->n_inliers = po.n_inliers;
     out->n_map_points = po.n_map_points;
+    return SS_OK;
+}
+
+int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height, int channels, int row_stride,
+             double timestamp, ss_pose *out)
+{
+    if (!c || !out) return SS_ERR_INVALID_ARG;
+    if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    ss_frame_result res;
+    int rc = ss_extract(c, camera_id, pix, width, height, channels, row_stride, timestamp, &res);
+    if (rc != SS_OK) return rc;
+    /* this frame's descriptors are still in HBM (frame 0 of the batch arrays) */
+    return track_step(c, camera_id, timestamp, c->desc, res.keypoints, res.n_keypoints, out);
+}
+
+int ss_track_features(ss_ctx *c, int camera_id, double timestamp, const void *d_descriptors, const ss_keypoint *keypoints,
+                      int n_keypoints, ss_pose *out)
+{
+    if (!c || !out || n_keypoints < 0) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    if (camera_id == 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing camera identifier.");
+    if (n_keypoints > 0 && (!d_descriptors || !keypoints)) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features: NULL feature arrays");
+    return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, keypoints, n_keypoints, out);
+}
+
+int ss_match_partial_device(ss_ctx *c, const void *d_query, int n_query, const void *d_train, int n_train, int64_t row_offset,
+                            void *d_part)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_query < 0 || n_train < 0 || row_offset < 0 || row_offset + n_train > 0x7FFFFFFFll)
+        return fail(c, SS_ERR_INVALID_ARG, "ss_match_partial_device: rows must fit 31 bits");
+    if (n_query == 0) return SS_OK;
+    if (!d_query || !d_part || (!d_train && n_train > 0)) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    int rc = grow(c, c->d_part_tmp, c->d_part_tmp_bytes, (size_t)n_query * 8);
+    if (rc != SS_OK) return rc;
+    int32_t *di = (int32_t *)c->d_part_tmp;
+    uint16_t *dd1 = (uint16_t *)(c->d_part_tmp + (size_t)n_query * 4), *dd2 = (uint16_t *)(c->d_part_tmp + (size_t)n_query * 6);
+    rc = ss_match_device(c, d_query, n_query, d_train, n_train, -1, 1, 1, 0, di, dd1, dd2);
+    if (rc != SS_OK) return rc;
+    ssk_pack_partial(c->stream, di, dd1, dd2, n_query, (int32_t)row_offset, d_part);
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_match_fold_device(ss_ctx *c, const void *d_parts, int n_parts, int n_query, int th, int ratio_num, int ratio_den,
+                         void *d_idx, void *d_d1, void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_parts < 1 || n_query < 0 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad fold arguments");
+    if (n_query == 0) return SS_OK;
+    if (!d_parts || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL fold buffer");
+    stage_timer t(c, "match_fold", (int64_t)n_parts * n_query * 8 + (int64_t)n_query * 8);
+    ssk_match_fold(c->stream, d_parts, n_parts, n_query, th, ratio_num, ratio_den, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2);
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_wait_stream(ss_ctx *c, void *hip_stream)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    hipEvent_t e = nullptr;
+    HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t r = hipEventRecord(e, (hipStream_t)hip_stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent(c->stream, e, 0);
+    (void)hipEventDestroy(e); /* destruction is deferred until the event has completed */
+    if (r != hipSuccess) return fail(c, SS_ERR_HIP, std::string("ss_wait_stream: ") + hipGetErrorString(r));
     return SS_OK;
 }
 
@@ -750,12 +839,17 @@ int ss_debug_fetch(ss_ctx *c, int what, int frame, int level, void *dst, int64_t
              * from now on this context keeps it */
             HIP_TRY(c, hipMalloc((void **)&c->score, (size_t)c->params.max_batch * g.block_bytes));
             ssk_fast_blur_nms(c->stream, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv,
-                              c->thdr, c->state, c->last_n_frames);
+                              c->thdr, c->state, c->last_n_frames, c->last_lvl0);
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         const uint8_t *base = what == 0 ? c->pyr : what == 1 ? c->blur : c->score;
         const int64_t need = (int64_t)L.w * L.h;
         if (dst_bytes < need) return fail(c, SS_ERR_INVALID_ARG, "ss_debug_fetch: dst too small");
+        if (what == 0 && level == 0 && c->last_lvl0.ptr) { /* level 0 was read in place from the caller's buffer */
+            HIP_TRY(c, hipMemcpy2D(dst, (size_t)L.w, c->last_lvl0.ptr + (int64_t)frame * c->last_lvl0.frame_stride,
+                                   (size_t)c->last_lvl0.pitch, (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
+            return (int)need;
+        }
         HIP_TRY(c, hipMemcpy2D(dst, (size_t)L.w, base + (size_t)frame * g.block_bytes + L.off, (size_t)L.pitch,
                                (size_t)L.w, (size_t)L.h, hipMemcpyDeviceToHost));
         return (int)need;

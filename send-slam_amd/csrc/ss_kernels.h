@@ -8,15 +8,23 @@
 #include "../../include/sendslam_orb.h"
 #include "ss_layout.h"
 
+/* level 0 read in place from the caller's buffer (ptr != NULL: 1-channel image, 16-byte aligned base, row and frame
+ * strides; no k_ingest pass), or from the pyramid block (ptr == NULL) */
+struct ss_lvl0 {
+    const uint8_t *ptr = nullptr;
+    int pitch = 0;
+    int64_t frame_stride = 0;
+};
+
 void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride, int64_t frame_stride,
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
-                int level, int n_frames);
+                int level, int n_frames, const ss_lvl0 &l0);
 /* K2 + K3a + K6a fused: FAST response map, in-window NMS into per-tile survivor sub-lists, blurred pyramid -- one
  * staged tile, no global atomics */
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
                        const uint32_t *tile_recs, const uint16_t *cinfo, uint32_t *tsurv, uint32_t *thdr, ss_level_state *state,
-                       int n_frames);
+                       int n_frames, const ss_lvl0 &l0);
 /* tile sub-lists -> per-cell buckets + count words (one thread per cell) */
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
                        const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames);
@@ -30,7 +38,7 @@ void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_l
                int32_t *n_kp, int32_t *level_counts, int32_t *frame_error, int n_frames);
 void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
                          const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
-                         uint8_t *desc, int n_frames);
+                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma);
 
 /* train split so that a launch has >> 256 workgroups and local indices fit 16 bits */
 int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len);
@@ -39,6 +47,12 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
                int nq_fixed, int nt_fixed, int64_t q_frame_stride_words, int64_t t_frame_stride_words,
                int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode, int th, int rnum, int rden,
                int out_stride, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2, int n_frames);
+/* (idx, d1, d2) of a raw match -> ss_match_part records with global rows (row_offset + idx) */
+void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, const uint16_t *d2, int n, int32_t row_offset,
+                      void *part);
+/* cross-shard fold: parts [n_parts][nq] in ascending row order -> final outputs (k_match_merge's rule) */
+void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int th, int rnum, int rden, int32_t *idx,
+                    uint16_t *d1, uint16_t *d2);
 /* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8

@@ -14,10 +14,14 @@
  *   K4  k_quadtree      ORBextractor::DistributeOctTree, one 4-wave workgroup per (frame, level)
  *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
- *   K7  k_match / k_match_merge   Hamming best / second best + ratio test
+ *   K7  k_match_mfma / k_match / k_match_stream / k_match_merge*   Hamming best / second best + ratio test
  *
- * Integer / byte work throughout: no MFMA (nothing here is a dense contraction).  Every
- * kernel takes the batch slot in blockIdx.y or .z so one launch covers a batch of frames.
+ * Integer / byte work throughout.  The one contraction on the path, the Hamming distance of K7, runs on
+ * the matrix cores as an exact i8 dot product (k_match_mfma); nothing else is
+ * reshaped into a GEMM.  Every kernel takes the batch slot in blockIdx.y or .z so one launch covers a
+ * batch of frames.  Level 0 of the pyramid is read IN PLACE from the caller's buffer when that is a
+ * 1-channel image with 16-byte aligned rows (lvl0 != NULL below); otherwise k_ingest writes it into the
+ * pyramid block first.
  * Float steps are single IEEE operations (-ffp-contract=off, ss_float_steps.h).
  */
 #include <cstddef>
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(256) void k_ingest_gray16(const uint8_t *__restrict
 /* K1: one pyramid step.  Host tables hold OpenCV's fixed-point taps (ss_geometry.cpp).   */
 /* ------------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
-                                                const ss_rtab *__restrict__ rtab, int level)
+                                                const ss_rtab *__restrict__ rtab, int level,
+                                                const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
@@ -123,9 +128,11 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dy >= D.h || dx4 >= D.w) return;
     uint8_t *base = pyr + (size_t)blockIdx.z * g->block_bytes;
-    const uint8_t *src = base + S.off;
+    const bool inplace = level == 1 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
+    const uint8_t *src = inplace ? lvl0 + (int64_t)blockIdx.z * lvl0_fs : base + S.off;
+    const int spitch = inplace ? lvl0_pitch : S.pitch;
     const ss_rtab ty = rtab[D.ytab_off + dy];
-    const uint8_t *r0 = src + (size_t)ty.s0 * S.pitch, *r1 = src + (size_t)ty.s1 * S.pitch;
+    const uint8_t *r0 = src + (size_t)ty.s0 * spitch, *r1 = src + (size_t)ty.s1 * spitch;
     const int b0 = ty.a0, b1 = ty.a1;
     uint32_t out = 0;
 #pragma unroll
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 #define RS_WORDS 24
 
 __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
-                                                    const ss_rtab *__restrict__ rtab, int level)
+                                                    const ss_rtab *__restrict__ rtab, int level,
+                                                    const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
     __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
     __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
@@ -158,7 +166,9 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int x0 = (tile % tiles_x) * SS_TILE_W, y0 = (tile / tiles_x) * RS_TILE_H;
     uint8_t *base = pyr + (size_t)blockIdx.y * g->block_bytes;
-    const uint8_t *src = base + S.off;
+    const bool inplace = level == 1 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
+    const uint8_t *src = inplace ? lvl0 + (int64_t)blockIdx.y * lvl0_fs : base + S.off;
+    const int spitch = inplace ? lvl0_pitch : S.pitch;
     /* the tile's tap tables go to LDS too (x table is padded past w; y rows are clamped) */
     if (threadIdx.x < SS_TILE_W) xt[threadIdx.x] = rtab[D.xtab_off + x0 + threadIdx.x];
     else if (threadIdx.x < SS_TILE_W + RS_TILE_H) yt[threadIdx.x - SS_TILE_W] = rtab[D.ytab_off + imin(y0 + (int)threadIdx.x - SS_TILE_W, D.h - 1)];
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
             const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
             const int gy = gy0 + r, gx = gx0 + 4 * c;
             /* rows and pitches are far below 2^24 and a level below 2^32 bytes: v_mad_u32_u24 instead of a 64-bit multiply */
-            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < S.pitch) ? *(const uint32_t *)(src + (__umul24((uint32_t)gy, (uint32_t)S.pitch) + (uint32_t)gx)) : 0u;
+            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < spitch) ? *(const uint32_t *)(src + (__umul24((uint32_t)gy, (uint32_t)spitch) + (uint32_t)gx)) : 0u;
         }
 #pragma unroll
         for (int it = 0; it < ROUNDS; it++) {
@@ -263,7 +273,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
                                                     uint32_t *__restrict__ tsurv,
                                                     uint32_t *__restrict__ thdr,
                                                     ss_level_state *__restrict__ state,
-                                                    uint8_t *__restrict__ blur)
+                                                    uint8_t *__restrict__ blur,
+                                                    const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
     /* `score` may be NULL: no later kernel reads the response map (it exists for stage-by-stage tests) */
     /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
@@ -286,7 +297,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const int xinfo_off = (int)tr[7], yinfo_off = (int)tr[8];
     const int frame = blockIdx.y;
     const size_t fb = (size_t)frame * g->block_bytes + tr[6];
-    const uint8_t *img = pyr + fb;
+    /* level 0 may live in the caller's buffer (own pitch); the blurred level is always written with the geometry's */
+    const bool inplace = level == 0 && lvl0 != nullptr;
+    const uint8_t *img = inplace ? lvl0 + (int64_t)frame * lvl0_fs : pyr + fb;
+    const int ipitch = inplace ? lvl0_pitch : pitch;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
@@ -308,14 +322,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const bool inner_x = x0 >= 4 && x0 + 68 <= w;
     if (inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h) {
         /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
-        const uint8_t *tile0 = img + (size_t)(y0 - 4) * pitch + (x0 - 4);
-        const uint32_t off = __umul24((uint32_t)ty, (uint32_t)pitch) + 4u * (uint32_t)tx;
+        const uint8_t *tile0 = img + (size_t)(y0 - 4) * ipitch + (x0 - 4);
+        const uint32_t off = __umul24((uint32_t)ty, (uint32_t)ipitch) + 4u * (uint32_t)tx;
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
             const int r = ty + (FT_THREADS / 16) * rr;
             if (r < FT_ROWS) {
-                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * pitch));
-                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * pitch) + 64);
+                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * ipitch));
+                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * ipitch) + 64);
             }
         }
     } else {
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         for (int rr = 0; rr < 3; rr++) {
             const int r = ty + (FT_THREADS / 16) * rr;
             if (r < FT_ROWS) {
-                const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * pitch;
+                const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * ipitch;
                 if (inner_x) {
                     lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
                     if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
@@ -1367,12 +1381,19 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
 static_assert(offsetof(ss_geom, ic_mask) % 16 == 0, "ic_mask is loaded as dwordx4");
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
 
+/* STEER_FMA: how the rotated tap coordinates cvRound(x*b + y*a), cvRound(x*a - y*b) are evaluated.  false = two
+ * products and one sum, each rounded (the C expression as written); true = what GCC's FMA contraction makes of it
+ * when upstream is built -O3 -march=native (CMakeLists.txt:10-13): the FIRST product fused into the sum,
+ * fma(x, b, y*a) and fma(x, a, -(y*b)).  Which one the reference binary runs is machine- and compiler-dependent and
+ * unpinned (tests/golden/ref_dump/README.md); both are implemented and tested against the oracle's two forms. */
+template <bool STEER_FMA>
 __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur,
                                                          const uint32_t *__restrict__ sel,
                                                          const uint32_t *__restrict__ kp_ref,
                                                          const int32_t *__restrict__ n_kp,
-                                                         ss_keypoint *__restrict__ kps, uint8_t *__restrict__ desc)
+                                                         ss_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
+                                                         const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
     /* all blocks of a frame on one XCD: keypoints whose patches share 64-B lines then share an L2 */
     const int logical = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
@@ -1401,13 +1422,15 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     const uint4 icm = ((const uint4 *)g->ic_mask)[lane];
     const int u0 = g->ic_u0[lane];
     {
-        const uint8_t *p0 = pyr + fb + (size_t)(ky - SS_HALF_PATCH) * pitch + px0;
+        const bool inplace = level == 0 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
+        const int ipitch = inplace ? lvl0_pitch : pitch;
+        const uint8_t *p0 = (inplace ? lvl0 + (int64_t)frame * lvl0_fs : pyr + fb) + (size_t)(ky - SS_HALF_PATCH) * ipitch + px0;
 #pragma unroll
         for (int it = 0; it < 5; it++) { /* 310 dwords = 4 full rounds of the wave + 54 lanes */
             const int idx = lane + WAVE * it;
             if (idx < 31 * 10) {
                 const int r = idx / 10, c = idx - r * 10;
-                patch[r][c] = *(const uint32_t *)(p0 + (__umul24((uint32_t)r, (uint32_t)pitch) + 4u * (uint32_t)c));
+                patch[r][c] = *(const uint32_t *)(p0 + (__umul24((uint32_t)r, (uint32_t)ipitch) + 4u * (uint32_t)c));
             }
         }
     }
@@ -1452,10 +1475,14 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
         const uint32_t pt = pat[k]; /* x0 y0 x1 y1 as int8 */
         const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
         const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
-        const int r0 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), RN_MAGIC));
-        const int c0 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), RN_MAGIC));
-        const int r1 = __float_as_int(__fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), RN_MAGIC));
-        const int c1 = __float_as_int(__fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), RN_MAGIC));
+        const float fr0 = STEER_FMA ? __fmaf_rn(x0, b, __fmul_rn(y0, a)) : __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+        const float fc0 = STEER_FMA ? __fmaf_rn(x0, a, -__fmul_rn(y0, b)) : __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+        const float fr1 = STEER_FMA ? __fmaf_rn(x1, b, __fmul_rn(y1, a)) : __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+        const float fc1 = STEER_FMA ? __fmaf_rn(x1, a, -__fmul_rn(y1, b)) : __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+        const int r0 = __float_as_int(__fadd_rn(fr0, RN_MAGIC));
+        const int c0 = __float_as_int(__fadd_rn(fc0, RN_MAGIC));
+        const int r1 = __float_as_int(__fadd_rn(fr1, RN_MAGIC));
+        const int c1 = __float_as_int(__fadd_rn(fc1, RN_MAGIC));
         off0[k] = (uint32_t)(__mul24(r0, pitch) + c0); /* (32 + row) * pitch + RN_BIAS + col: positive, below 2^31 */
         off1[k] = (uint32_t)(__mul24(r1, pitch) + c1);
     }
@@ -1875,6 +1902,22 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
     d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
 }
 
+/* raw local match of a database shard -> the 8-byte records ranks exchange (include/sendslam_orb.h ss_match_part) */
+static_assert(sizeof(match_partial) == sizeof(ss_match_part) && offsetof(match_partial, j1) == offsetof(ss_match_part, row),
+              "the chunk partial IS the cross-shard record");
+__global__ __launch_bounds__(256) void k_pack_partial(const int32_t *__restrict__ idx, const uint16_t *__restrict__ d1,
+                                                      const uint16_t *__restrict__ d2, int n, int32_t row_offset,
+                                                      match_partial *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    match_partial mp;
+    mp.d1 = d1[i];
+    mp.d2 = d2[i];
+    mp.j1 = idx[i] < 0 ? -1 : idx[i] + row_offset;
+    out[i] = mp;
+}
+
 /* Same fold for MANY chunks (large databases): one wave per query, lanes stride over the chunks,
  * then a cross-lane fold on the 64-bit key (distance, global row) -- a lower row wins a tie, the
  * second best is the smallest of all second distances and the losing first distances. */
@@ -2020,25 +2063,25 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
 }
 
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
-                int level, int n_frames)
+                int level, int n_frames, const ss_lvl0 &l0)
 {
     /* source window of a 64x64 tile: (64 * scale + 1 + 3 alignment) bytes x (64 * scale + 2) rows */
     const float sx = (float)hg.lv[level - 1].w / (float)hg.lv[level].w, sy = (float)hg.lv[level - 1].h / (float)hg.lv[level].h;
     if (64.f * sx + 6.f <= 4.f * RS_WORDS && (float)RS_TILE_H * sy + 3.f <= (float)RS_ROWS) {
         dim3 grid(((hg.lv[level].w + SS_TILE_W - 1) / SS_TILE_W) * ((hg.lv[level].h + RS_TILE_H - 1) / RS_TILE_H), n_frames);
-        hipLaunchKernelGGL(k_resize_lds, grid, dim3(256), 0, s, pyr, dg, rtab, level);
+        hipLaunchKernelGGL(k_resize_lds, grid, dim3(256), 0, s, pyr, dg, rtab, level, l0.ptr, l0.pitch, l0.frame_stride);
     } else {
         dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level, l0.ptr, l0.pitch, l0.frame_stride);
     }
 }
 
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,
                        const uint32_t *tile_recs, const uint16_t *cinfo, uint32_t *tsurv, uint32_t *thdr, ss_level_state *state,
-                       int n_frames)
+                       int n_frames, const ss_lvl0 &l0)
 {
     hipLaunchKernelGGL(k_fast_score, dim3(hg.tiles2_total, n_frames), dim3(FT_THREADS), 0, s, pyr, score, dg, tile_recs, cinfo, tsurv, thdr,
-                       state, blur);
+                       state, blur, l0.ptr, l0.pitch, l0.frame_stride);
 }
 void ssk_bucket_gather(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint32_t *cell_units, const uint32_t *tsurv,
                        const uint32_t *thdr, uint32_t *bucket, uint32_t *cell_cnt, ss_level_state *state, int n_frames)
@@ -2069,10 +2112,14 @@ void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_l
 
 void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
                          const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
-                         uint8_t *desc, int n_frames)
+                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma)
 {
-    hipLaunchKernelGGL(k_orient_describe, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
-                       n_kp, kps, desc);
+    if (steer_fma)
+        hipLaunchKernelGGL(k_orient_describe<true>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
+                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride);
+    else
+        hipLaunchKernelGGL(k_orient_describe<false>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
+                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride);
 }
 
 /* which form of the matrix-core kernel: a single large database has the chip to itself (NU = 2), batches of frames share it */
@@ -2155,6 +2202,19 @@ bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int n
     hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
                        idx, d1, d2);
     return true;
+}
+
+void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, const uint16_t *d2, int n, int32_t row_offset,
+                      void *part)
+{
+    hipLaunchKernelGGL(k_pack_partial, dim3((n + 255) / 256), dim3(256), 0, s, idx, d1, d2, n, row_offset, (match_partial *)part);
+}
+
+void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int th, int rnum, int rden, int32_t *idx,
+                    uint16_t *d1, uint16_t *d2)
+{
+    hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256, 1), dim3(256), 0, s, (const match_partial *)parts, (const int32_t *)nullptr,
+                       nq, n_parts, th, rnum, rden, nq, idx, d1, d2);
 }
 
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n)

@@ -15,22 +15,26 @@ import numpy as np
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
 SS_MAX_LEVELS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SS_OK = 0
 SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3, -4
 SS_ERR_OVERFLOW, SS_ERR_NOT_CALIBRATED, SS_ERR_BAD_FRAME, SS_ERR_NO_MEMORY, SS_ERR_STATE = -5, -6, -7, -8, -9
+SS_ERR_BUSY = -10
 
 EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy", "ss_last_error",
            "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_fetch_frame", "ss_match",
            "ss_match_device", "ss_match_batch_device", "ss_track", "ss_track_reset", "ss_synchronize", "ss_get_stream",
-           "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort"]
+           "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort",
+           "ss_track_features", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
+           "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
+           "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight"]
 
 
 class OrbParams(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("lapping_x0", C.c_int32),
-                ("lapping_x1", C.c_int32), ("max_batch", C.c_int32)]
+                ("lapping_x1", C.c_int32), ("max_batch", C.c_int32), ("steer_fma", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -49,7 +53,8 @@ class FrameResult(C.Structure):
 
 class BatchView(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("keypoints", C.c_void_p),
-                ("descriptors", C.c_void_p), ("n_keypoints", C.c_void_p), ("level_counts", C.c_void_p)]
+                ("descriptors", C.c_void_p), ("n_keypoints", C.c_void_p), ("level_counts", C.c_void_p),
+                ("frame_error", C.c_void_p)]
 
 
 class StageStats(C.Structure):
@@ -61,6 +66,24 @@ class Pose(C.Structure):
     _fields_ = [("tracking_state", C.c_int32), ("camera_id", C.c_int32), ("timestamp", C.c_double),
                 ("position", C.c_double * 3), ("quaternion", C.c_double * 4), ("n_keypoints", C.c_int32),
                 ("n_matches", C.c_int32), ("n_inliers", C.c_int32), ("n_map_points", C.c_int32)]
+
+
+class PipeConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("batch", C.c_int32),
+                ("depth", C.c_int32), ("match_mode", C.c_int32), ("match_th", C.c_int32), ("ratio_num", C.c_int32),
+                ("ratio_den", C.c_int32), ("copy_threads", C.c_int32)]
+
+
+class PipeSlot(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("pixels", C.c_void_p), ("row_stride", C.c_int64), ("frame_stride", C.c_int64)]
+
+
+class PipeResult(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("n_frames", C.c_int32), ("kp_capacity", C.c_int32), ("sequence", C.c_uint64),
+                ("status", C.c_void_p), ("camera_id", C.c_void_p), ("timestamp", C.c_void_p),
+                ("n_keypoints", C.c_void_p), ("level_counts", C.c_void_p), ("keypoints", C.c_void_p),
+                ("descriptors", C.c_void_p), ("match_idx", C.c_void_p), ("match_d1", C.c_void_p),
+                ("match_d2", C.c_void_p), ("d_descriptors", C.c_void_p)]
 
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -124,6 +147,23 @@ def load():
     lib.ss_stats.argtypes = [C.c_void_p, C.POINTER(StageStats), C.c_int]
     lib.ss_debug_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]
     lib.ss_debug_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.ss_track_features.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Pose)]
+    lib.ss_match_partial_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
+    lib.ss_match_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ss_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ss_pipe_create.argtypes = [C.c_int, C.POINTER(OrbParams), C.POINTER(Camera), C.POINTER(PipeConfig),
+                                   C.POINTER(C.c_void_p)]
+    lib.ss_pipe_destroy.argtypes = [C.c_void_p]
+    lib.ss_pipe_last_error.restype = C.c_char_p
+    lib.ss_pipe_last_error.argtypes = [C.c_void_p]
+    lib.ss_pipe_acquire.argtypes = [C.c_void_p, C.POINTER(PipeSlot)]
+    lib.ss_pipe_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ss_pipe_submit_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.ss_pipe_wait.argtypes = [C.c_void_p, C.POINTER(PipeResult)]
+    lib.ss_pipe_poll.argtypes = [C.c_void_p, C.POINTER(PipeResult)]
+    lib.ss_pipe_release.argtypes = [C.c_void_p, C.c_int]
+    lib.ss_pipe_in_flight.argtypes = [C.c_void_p]
     if lib.ss_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI {lib.ss_abi_version()} != {ABI_VERSION}")
     _lib = lib
@@ -219,6 +259,17 @@ class OrbContext:
                 "n_keypoints": po.n_keypoints, "n_matches": po.n_matches, "n_inliers": po.n_inliers,
                 "n_map_points": po.n_map_points}
 
+    def track_features(self, d_desc: int, kps: np.ndarray, camera_id: int = 1, timestamp: float = 0.0) -> dict:
+        """Pose step alone: descriptors already on the device (n x 32 B at d_desc), keypoints KP_DTYPE[n] on the host."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        po = Pose()
+        self._check(self._lib.ss_track_features(self._h, int(camera_id), float(timestamp), C.c_void_p(d_desc),
+                                                kps.ctypes.data, len(kps), C.byref(po)))
+        return {"state": po.tracking_state, "camera_id": po.camera_id, "timestamp": po.timestamp,
+                "position": np.array(list(po.position)), "quaternion": np.array(list(po.quaternion)),
+                "n_keypoints": po.n_keypoints, "n_matches": po.n_matches, "n_inliers": po.n_inliers,
+                "n_map_points": po.n_map_points}
+
     def track_reset(self):
         self._check(self._lib.ss_track_reset(self._h))
 
@@ -258,6 +309,20 @@ class OrbContext:
         self._check(self._lib.ss_match_batch_device(self._h, mode, th, ratio_num, ratio_den, C.c_void_p(d_idx),
                                                     C.c_void_p(d_d1), C.c_void_p(d_d2)))
 
+    def match_partial_device(self, d_q: int, nq: int, d_t: int, nt: int, row_offset: int, d_part: int):
+        """Raw local match of a database shard -> nq 8-byte ss_match_part records (global rows) at d_part."""
+        self._check(self._lib.ss_match_partial_device(self._h, C.c_void_p(d_q), nq, C.c_void_p(d_t), nt, int(row_offset),
+                                                      C.c_void_p(d_part)))
+
+    def match_fold_device(self, d_parts: int, n_parts: int, nq: int, d_idx: int, d_d1: int, d_d2: int, th: int = 50,
+                          ratio_num: int = 9, ratio_den: int = 10):
+        self._check(self._lib.ss_match_fold_device(self._h, C.c_void_p(d_parts), n_parts, nq, th, ratio_num, ratio_den,
+                                                   C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)))
+
+    def wait_stream(self, hip_stream: int):
+        """Orders this context's stream after everything enqueued so far on another stream of the device."""
+        self._check(self._lib.ss_wait_stream(self._h, C.c_void_p(hip_stream)))
+
     def synchronize(self):
         self._check(self._lib.ss_synchronize(self._h))
 
@@ -283,6 +348,122 @@ class OrbContext:
         out = np.empty(shape, dtype)
         n = self._check(self._lib.ss_debug_fetch(self._h, what, frame, level, out.ctypes.data, out.nbytes))
         return out.reshape(-1)[: n // out.itemsize]
+
+
+class Pipe:
+    """ss_pipe_*: ring of pinned slots; host frames in, host keypoints / descriptors / matches out, copies and
+    kernels of different batches overlapped.  Arrays of a result are views of the slot's pinned memory: valid until
+    release(slot)."""
+
+    def __init__(self, device: int, width: int, height: int, channels: int = 1, batch: int = 64, depth: int = 4,
+                 match_mode: int = 0, copy_threads: int = 0, cam: Optional[Camera] = None, **params):
+        self._lib = load()
+        self.params = default_params(**params)
+        self.cfg = PipeConfig(width=width, height=height, channels=channels, batch=batch, depth=depth,
+                              match_mode=match_mode, copy_threads=copy_threads)
+        h = C.c_void_p()
+        rc = self._lib.ss_pipe_create(int(device), C.byref(self.params), C.byref(cam) if cam is not None else None,
+                                      C.byref(self.cfg), C.byref(h))
+        if rc != SS_OK:
+            raise OrbError(rc, (self._lib.ss_pipe_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_pipe_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise OrbError(rc, (self._lib.ss_pipe_last_error(self._h) or b"").decode())
+        return rc
+
+    def acquire(self):
+        """-> (slot id, uint8 view [batch, height, row_stride] of the slot's pinned pixels) or None when busy"""
+        sl = PipeSlot()
+        rc = self._lib.ss_pipe_acquire(self._h, C.byref(sl))
+        if rc == SS_ERR_BUSY:
+            return None
+        self._check(rc)
+        n = self.cfg.batch * sl.frame_stride
+        buf = (C.c_uint8 * n).from_address(sl.pixels)
+        return sl.slot, np.frombuffer(buf, np.uint8).reshape(self.cfg.batch, self.cfg.height, sl.row_stride)
+
+    def submit(self, slot: int, n_frames: int, camera_ids=None, timestamps=None):
+        ci = None if camera_ids is None else np.ascontiguousarray(camera_ids, np.int32)
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        self._check(self._lib.ss_pipe_submit(self._h, slot, n_frames, None if ci is None else ci.ctypes.data,
+                                             None if ts is None else ts.ctypes.data))
+
+    def submit_frames(self, frames, camera_ids=None, timestamps=None, row_stride: Optional[int] = None) -> bool:
+        """frames: sequence of uint8 arrays of the pipe's shape (None = a bad frame).  False when no slot is free."""
+        keep = [None if f is None else np.ascontiguousarray(f, np.uint8) for f in frames]
+        ptrs = (C.c_void_p * len(keep))(*[None if f is None else f.ctypes.data for f in keep])
+        rs = self.cfg.width * self.cfg.channels if row_stride is None else row_stride
+        ci = None if camera_ids is None else np.ascontiguousarray(camera_ids, np.int32)
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        rc = self._lib.ss_pipe_submit_frames(self._h, ptrs, len(keep), rs, None if ci is None else ci.ctypes.data,
+                                             None if ts is None else ts.ctypes.data)
+        if rc == SS_ERR_BUSY:
+            return False
+        self._check(rc)
+        return True
+
+    def submit_batch_array(self, batch: np.ndarray, camera_ids=None, timestamps=None) -> bool:
+        """batch: one contiguous uint8 array [n, height, width(, channels)]: frame pointers without per-frame Python work"""
+        assert batch.dtype == np.uint8 and batch.flags.c_contiguous
+        n = batch.shape[0]
+        fs = batch.strides[0]
+        base = batch.ctypes.data
+        ptrs = (C.c_void_p * n)(*[base + i * fs for i in range(n)])
+        ci = None if camera_ids is None else np.ascontiguousarray(camera_ids, np.int32)
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        rc = self._lib.ss_pipe_submit_frames(self._h, ptrs, n, self.cfg.width * self.cfg.channels,
+                                             None if ci is None else ci.ctypes.data, None if ts is None else ts.ctypes.data)
+        if rc == SS_ERR_BUSY:
+            return False
+        self._check(rc)
+        return True
+
+    def _result(self, r: PipeResult) -> dict:
+        n, k = r.n_frames, r.kp_capacity
+
+        def view(ptr, dtype, shape):
+            if not ptr:
+                return None
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype).reshape(shape)
+        return {"slot": r.slot, "n_frames": n, "kp_capacity": k, "sequence": r.sequence,
+                "status": view(r.status, np.int32, (n,)), "camera_id": view(r.camera_id, np.int32, (n,)),
+                "timestamp": view(r.timestamp, np.float64, (n,)), "n_keypoints": view(r.n_keypoints, np.int32, (n,)),
+                "level_counts": view(r.level_counts, np.int32, (n, SS_MAX_LEVELS)),
+                "keypoints": view(r.keypoints, KP_DTYPE, (n, k)), "descriptors": view(r.descriptors, np.uint8, (n, k, 32)),
+                "match_idx": view(r.match_idx, np.int32, (n, k)), "match_d1": view(r.match_d1, np.uint16, (n, k)),
+                "match_d2": view(r.match_d2, np.uint16, (n, k)), "d_descriptors": r.d_descriptors}
+
+    def wait(self) -> dict:
+        r = PipeResult()
+        self._check(self._lib.ss_pipe_wait(self._h, C.byref(r)))
+        return self._result(r)
+
+    def poll(self) -> Optional[dict]:
+        r = PipeResult()
+        rc = self._check(self._lib.ss_pipe_poll(self._h, C.byref(r)))
+        return self._result(r) if rc == 1 else None
+
+    def release(self, slot: int):
+        self._check(self._lib.ss_pipe_release(self._h, slot))
+
+    def in_flight(self) -> int:
+        return self._check(self._lib.ss_pipe_in_flight(self._h))
 
 
 def _debug_sort(self, size, ulx):

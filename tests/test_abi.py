@@ -30,18 +30,21 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sendslam_orb.h but not exported"
     assert sorted(binding.EXPORTS) == names
-    assert lib.ss_abi_version() == 2
+    assert lib.ss_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(binding.OrbParams) == 32
+    assert C.sizeof(binding.OrbParams) == 36
     assert C.sizeof(binding.Camera) == 16 + 8 * 8 + 8 + 8 + 8 + 24
     assert binding.KP_DTYPE.itemsize == 24
     assert C.sizeof(binding.StageStats) == 32 + 8 + 24 + 8
     assert C.sizeof(binding.Pose) == 8 + 8 + 24 + 32 + 16
+    assert C.sizeof(binding.BatchView) == 8 + 5 * 8
+    assert C.sizeof(binding.PipeConfig) == 40 and C.sizeof(binding.PipeSlot) == 32
+    assert C.sizeof(binding.PipeResult) == 16 + 8 + 11 * 8
     p = binding.default_params()
     # reference YAML literals, orbslam3_mono_networked.cc:193-206
-    assert (p.n_features, p.n_levels, p.ini_th_fast, p.min_th_fast, p.max_batch) == (1250, 8, 20, 7, 1)
+    assert (p.n_features, p.n_levels, p.ini_th_fast, p.min_th_fast, p.max_batch, p.steer_fma) == (1250, 8, 20, 7, 1, 0)
     assert abs(p.scale_factor - 1.2) < 1e-6 and (p.lapping_x0, p.lapping_x1) == (0, 1000)
 
 
