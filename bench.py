@@ -4,20 +4,32 @@
 
 A "step" is one pass of the hot path over ONE BATCH of frames already resident in HBM:
 ss_extract_batch_device (pyramid, FAST + NMS, quadtree, orientation, blur, rBRIEF) followed by
-ss_match_batch_device (self-match, j == i excluded).  With N GPUs every rank runs the same step
-on its own camera batch (cameras shard one per GPU, no data-path collective): weak scaling,
-value = frames all ranks processed / max-over-ranks time.
+ss_match_batch_device (self-match, j == i excluded).  Steps rotate over several DISTINCT device batches
+whose total exceeds the 256 MB Infinity Cache, so the frames of a step come from HBM, and over a few
+contexts (camera batches in flight, each with its own stream and buffers).  With N GPUs every rank
+runs the same steps on its own camera batches (cameras shard one per GPU, no data-path collective):
+weak scaling, value = frames all ranks processed / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run ... bench.py --workload stereo|loop_closure   (configs 4 and 5)
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel: ALGORITHMIC bytes per launch / HIP-event mean duration,
-                measured on the context's own stream inside the timed region
-  kernels       the same for every stage
-  cpu_baseline  the CPU oracle (a port: the reference's ORB-SLAM3 cannot be built here,
-                DESIGN.md) timed on this host on a bounded sample of the same frames, 1 thread
-                like the reference shim (orbslam3_mono_networked.cc:594), plus all cores
+  roofline               dominant kernel: ALGORITHMIC bytes per launch / HIP-event mean duration on its own stream
+  valu_roofline          the same kernel against the resource that binds it (integer VALU issue)
+  match_roofline         the Hamming-match kernel of the metric (2000 x 2000 per frame) against the int8 MFMA peak
+  match_stream_roofline  the Hamming-match kernel in the database-streaming regime (1 and 4 queries against 20 M
+                         descriptors = 640 MB): achieved HBM GB/s against the 8 TB/s peak -- the north star's
+                         ">= 60 % HBM roofline on the Hamming-match kernel"
+  value_spread           rate of each 1/25th of the timed region (HIP events, no drain between them)
+  host_pipeline          the same step fed from HOST memory through the pinned ring of the C ABI (ss_pipe_*):
+                         frames/s and PCIe GB/s, copies overlapped with the kernels.  Never `value`.
+  kernels                per-stage durations
+  cpu_baseline           the CPU oracle (a port: the reference's ORB-SLAM3 cannot be built here) timed on
+                         this host on a bounded sample of the same frames, 1 thread like the reference shim
+                         (orbslam3_mono_networked.cc:594), plus all cores
+Parity: "parity_checked_vs_oracle" compares frames of EVERY context's last timed batch with the oracle = the
+committed CPU restatement (parity with the real ORB-SLAM3 binary is unpinned).
 """
 import argparse
 import json
@@ -34,28 +46,29 @@ import numpy as np  # noqa: E402
 
 INT8_MFMA_PEAK_OPS = 5.0e15  # dense int8 MFMA, 2 x the 2.5e15 dense bf16 peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+CACHE_BYTES = 256 << 20  # Infinity Cache: the rotating device batches must exceed it
 
 
-def make_frames(rank, batch, w, h):
-    """batch frames = ceil(batch/8) scenes x 8 time steps (consecutive frames move by (3,-2) px)."""
+def make_frames(rank, n_sets, batch, w, h):
+    """n_sets x batch DISTINCT frames: set s = scene (rank, s) at time steps 0 .. batch-1 (consecutive frames move
+    by (3,-2) px and carry fresh noise)."""
     from send_slam_amd import synth
-    out = np.empty((batch, h, w), np.uint8)
-    n_scenes = (batch + 7) // 8
-    i = 0
-    for s in range(n_scenes):
+    out = np.empty((n_sets, batch, h, w), np.uint8)
+    for s in range(n_sets):
         seed = 1000 * rank + s
         sc = synth.scene(seed, w, h)
-        for t in range(8):
-            if i >= batch:
-                break
-            out[i] = synth.frame_from_scene(sc, seed, w, h, t)
-            i += 1
+        for t in range(batch):
+            out[s, t] = synth.frame_from_scene(sc, seed, w, h, t)
     return out
+
+
+_CPU_FRAMES = None
 
 
 def _cpu_one(args):
     from oracle import orb_oracle as O
-    frame, nf = args
+    i, nf = args
+    frame = _CPU_FRAMES[i]
     p = O.default_params(n_features=nf)
     t0 = time.perf_counter()
     kps, desc, _ = O.extract(frame, p)
@@ -63,17 +76,27 @@ def _cpu_one(args):
     return time.perf_counter() - t0, kps, desc, idx, d1, d2
 
 
+def _cpu_time_only(args):
+    return _cpu_one(args)[0]
+
+
+def _noop(_):
+    return 0
+
+
 def cpu_baseline(frames, nf, budget_s=12.0):
     """Oracle timed on host cores BEFORE the GPU is touched (a process pool forks).
-    Returns the JSON object and the per-frame oracle outputs for the parity spot-check."""
+    Returns the JSON object and the per-frame oracle outputs for the parity check."""
     import multiprocessing as mp
     from oracle import orb_oracle as O
+    global _CPU_FRAMES
+    _CPU_FRAMES = frames
     O.build()
     times, outs = [], []
-    _cpu_one((frames[0], nf))  # warm-up (page in, first malloc)
+    _cpu_one((0, nf))  # warm-up (page in, first malloc)
     t_start = time.perf_counter()
     for i in range(len(frames)):
-        r = _cpu_one((frames[i], nf))
+        r = _cpu_one((i, nf))
         times.append(r[0])
         outs.append(r[1:])
         if time.perf_counter() - t_start > budget_s / 2 and len(times) >= 5:
@@ -81,32 +104,34 @@ def cpu_baseline(frames, nf, budget_s=12.0):
     times.sort()
     median = times[len(times) // 2]  # the shim's median rule (orbslam3_mono_networked.cc:661)
     cores = len(os.sched_getaffinity(0))
-    all_cores = None
+    all_cores = n_jobs = None
     if cores > 1:
-        n_jobs = min(len(frames), max(cores, int(cores * (budget_s / 2) / max(median, 1e-3))))
-        n_jobs = min(n_jobs, 4 * cores)
-        jobs = [(frames[i % len(frames)], nf) for i in range(n_jobs)]
+        # >= 4 jobs per core, frames reused round-robin (the workers inherit them by fork: nothing is pickled in),
+        # pool started and warmed before the clock starts
+        n_jobs = max(4 * cores, int(cores * (budget_s / 2) / max(median, 1e-3)))
+        n_jobs = min(n_jobs, 16 * cores)
+        jobs = [(i % len(frames), nf) for i in range(n_jobs)]
         with mp.get_context("fork").Pool(cores) as pool:
+            pool.map(_noop, range(4 * cores), chunksize=1)
             t0 = time.perf_counter()
-            pool.map(_cpu_one, jobs, chunksize=1)
+            pool.map(_cpu_time_only, jobs, chunksize=1)
             all_cores = n_jobs / (time.perf_counter() - t0)
     obj = {"value": round(1.0 / median, 3), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"{len(times)} of the bench's own 1280x720 frames, extract + self-match, median per frame "
                      f"{median * 1e3:.1f} ms, 1 thread (oracle/orb_oracle.c, -O3)",
-           "all_cores_value": None if all_cores is None else round(all_cores, 2), "all_cores": cores}
+           "all_cores_value": None if all_cores is None else round(all_cores, 2), "all_cores": cores,
+           "all_cores_sample": None if n_jobs is None else f"{n_jobs} frame jobs over a warmed pool of {cores} processes, one frame per job"}
     return obj, outs
 
 
-def bench_loop_closure(a):
-    """Config 5 of BASELINE.json: query-vs-all Hamming match against a keyframe database partitioned
-    in contiguous slabs over the ranks; one broadcast + one all_gather per query (multi.py)."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def dist_setup(world):
     import torch
     import torch.distributed as dist
-    from send_slam_amd import binding, multi
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # rehearsal hooks for a ONE-GPU box (tests / gpurun): SENDSLAM_BENCH_BACKEND=gloo moves the collectives to the
+    # CPU, SENDSLAM_BENCH_ONE_DEVICE=1 puts every rank on device 0.
     backend = os.environ.get("SENDSLAM_BENCH_BACKEND", "nccl")
     if os.environ.get("SENDSLAM_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
@@ -114,10 +139,42 @@ def bench_loop_closure(a):
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, dev, backend
+
+
+def max_over_ranks(elapsed, world, dev, backend):
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def stage_roofline(stats, name, peak=HBM_PEAK_GBS):
+    s = next((x for x in stats if x["name"] == name), None)
+    if not s or not s["launches"] or s["mean_ms"] <= 0:
+        return None
+    gbs = s["algorithmic_bytes"] / (s["mean_ms"] * 1e-3) / 1e9
+    return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "frac": round(gbs / peak, 4),
+            "kernel_ms": round(s["mean_ms"], 5), "launches": s["launches"], "algorithmic_bytes_per_launch": s["algorithmic_bytes"]}
+
+
+def bench_loop_closure(a):
+    """Config 5 of BASELINE.json: query-vs-all Hamming match against a keyframe database partitioned in contiguous slabs
+    over the ranks; per query one broadcast, ss_match_partial_device, one all_gather of world x nq x 8 B and
+    ss_match_fold_device, all ordered on the context's stream (multi.loop_closure_query_device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, dev, backend = dist_setup(world)
+    import torch
+    import torch.distributed as dist
+    from send_slam_amd import binding, multi
     n_db, nq = 10000 * 2000, a.features
     b, e = multi.slab(n_db, world, rank)
     gen = torch.Generator(device=dev)
@@ -125,107 +182,328 @@ def bench_loop_closure(a):
     db = torch.randint(0, 256, (e - b, 32), dtype=torch.uint8, device=dev, generator=gen)
     query = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gen)
     ctx = binding.OrbContext(local_rank)
-    local = multi.hip_local_match(ctx)
-    for _ in range(a.warmup):
-        multi.loop_closure_query(query, db, b, local)
+    out = (torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, dtype=torch.int16, device=dev),
+           torch.empty(nq, dtype=torch.int16, device=dev))
+    steps = a.steps if a.steps else 20
+    for _ in range(max(a.warmup, 1)):
+        multi.loop_closure_query_device(ctx, query, db, b, out=out)
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        multi.loop_closure_query_device(ctx, query, db, b, out=out)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+    stats = ctx.stats()
+    ctx.profile(False)
+    if rank == 0:
+        mk = next((s for s in stats if s["name"] == "match"), None)
+        pairs = float(nq) * (e - b)
+        roof = None
+        if mk and mk["mean_ms"] > 0:
+            t = mk["mean_ms"] * 1e-3
+            roof = {"kernel": "match (k_match_mfma<2> + merge, this rank's slab)", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
+                    "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
+                    "kernel_ms": round(mk["mean_ms"], 4), "traffic": None}
+        print(json.dumps({
+            "metric": "loop-closure queries/sec (2000 descriptors vs 10k-keyframe database)", "value": round(steps / elapsed, 3),
+            "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
+                                   "raw local match -> 8-byte records, all_gather, fold kernel", "parallelism": f"db slabs x {world}"},
+            "roofline": roof, "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
+            "pairs_per_s": float(f"{nq * n_db * steps / elapsed:.4g}")}))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_stereo(a):
+    """Config 4 of BASELINE.json: left / right 1920x1080 cameras on two GPUs.  A step = each rank extracts a batch of
+    frames of ITS eye, one all_gather of the fixed-size descriptor blocks ([B][kp_capacity][32] + counts) over xGMI,
+    then each rank matches its frames against the peer eye's frames of the same instant (ss_match_pairs_device).
+    Everything is ordered on the context's stream; value = stereo pairs per second."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != 2:
+        sys.exit("bench.py --workload stereo needs exactly 2 ranks (torch.distributed.run --nproc-per-node 2)")
+    rank, local_rank, dev, backend = dist_setup(world)
+    import torch
+    import torch.distributed as dist
+    from send_slam_amd import binding, multi, synth
+    w, h, nf, B = 1920, 1080, a.features, (a.batch or 16)
+    # the right eye sees the left eye's scene 24 px further left (a fronto-parallel plane)
+    sc = synth.scene(4242, w + 64, h)
+    frames = np.stack([np.clip(sc[synth._MARGIN + 2 * t:synth._MARGIN + 2 * t + h, synth._MARGIN + 24 * rank + 3 * t:synth._MARGIN + 24 * rank + 3 * t + w], 0, 255).astype(np.uint8)
+                       for t in range(B)])
+    d_frames = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+    ctx = binding.OrbContext(local_rank, n_features=nf, max_batch=B)
+    ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+    ctx.synchronize()
+    kcap = ctx.batch_view().kp_capacity
+    view = ctx.batch_view()
+
+    def dev_tensor(ptr, shape, dtype):
+        """torch view of a device array the library owns (no copy)"""
+        class _Wrap:
+            __cuda_array_interface__ = {"shape": tuple(shape), "typestr": {torch.uint8: "|u1", torch.int32: "<i4"}[dtype],
+                                        "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Wrap(), device=dev)
+    own_desc = dev_tensor(view.descriptors, (B, kcap, 32), torch.uint8)
+    own_n = dev_tensor(view.n_keypoints, (B,), torch.int32)
+    gathered_desc = torch.empty((2, B, kcap, 32), dtype=torch.uint8, device=dev)
+    gathered_n = torch.empty((2, B), dtype=torch.int32, device=dev)
+    o_idx = torch.empty((B, kcap), dtype=torch.int32, device=dev)
+    o_d1 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
+    o_d2 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
+    peer = 1 - rank
+
+    def step():
+        ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+        with multi.on_ctx_stream(ctx, dev):
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered_desc, own_desc)
+                dist.all_gather_into_tensor(gathered_n, own_n)
+            else:  # CPU rehearsal of the exchange
+                ctx.synchronize()
+                outs = [torch.empty((B, kcap, 32), dtype=torch.uint8) for _ in range(2)]
+                dist.all_gather(outs, own_desc.cpu())
+                gathered_desc.copy_(torch.stack(outs))
+                outs = [torch.empty((B,), dtype=torch.int32) for _ in range(2)]
+                dist.all_gather(outs, own_n.cpu())
+                gathered_n.copy_(torch.stack(outs))
+            ctx.match_pairs_device(own_desc.data_ptr(), own_n.data_ptr(), gathered_desc[peer].data_ptr(), gathered_n[peer].data_ptr(),
+                                   B, kcap, o_idx.data_ptr(), o_d1.data_ptr(), o_d2.data_ptr())
+
+    steps = a.steps if a.steps else 20
+    for _ in range(max(a.warmup, 1)):
+        step()
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        idx, d1, d2 = multi.loop_closure_query(query, db, b, local)
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+    stats = ctx.stats()
+    ctx.profile(False)
+    # sanity on the measured configuration: most left keypoints find their right-eye partner 24 px away
+    n_own = own_n.cpu().numpy()
+    idx = o_idx.cpu().numpy()
+    matched = float(np.mean([(idx[b, :n_own[b]] >= 0).mean() for b in range(B)]))
     if rank == 0:
         print(json.dumps({
-            "metric": "loop-closure queries/sec (2000 descriptors vs 10k-keyframe database)", "value": round(a.steps / elapsed, 3),
-            "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
-                                   "raw local match + all_gather of (d1, j1, d2) + fold", "parallelism": f"db slabs x {world}"},
-            "pairs_per_s": float(f"{nq * n_db * a.steps / elapsed:.4g}")}))
+            "metric": "stereo pairs/sec ORB extract + cross-camera match @1920x1080, 2000 kp/eye", "value": round(B * steps / elapsed, 2),
+            "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"stereo {w}x{h}: one eye per GPU, batches of {B} frames, all_gather of {B * kcap * 32} B descriptor blocks + counts, "
+                                   "cross-eye match", "parallelism": "2 ranks, one all_gather per step", "backend": backend},
+            "roofline": stage_roofline(stats, "fast_blur_nms"),
+            "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
+            "fraction_of_keypoints_matched_across_eyes": round(matched, 3)}))
     ctx.close()
     dist.destroy_process_group()
+
+
+def bench_match_stream(binding, torch, dev, local_rank, launches=24):
+    """The Hamming-match kernel in the regime where HBM bounds it (SURVEY.md section 8(d), config 5 with a handful of
+    queries): 1 and 4 query descriptors against 20 M database descriptors (640 MB, read exactly once per launch)."""
+    n_db = 10000 * 2000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    db = torch.randint(0, 256, (n_db, 32), dtype=torch.uint8, device=dev, generator=gen)
+    out = {}
+    with binding.OrbContext(local_rank) as ctx:
+        for nq in (1, 4):
+            q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gen)
+            idx = torch.empty(nq, dtype=torch.int32, device=dev)
+            d1 = torch.empty(nq, dtype=torch.int16, device=dev)
+            d2 = torch.empty(nq, dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                ctx.match_device(q.data_ptr(), nq, db.data_ptr(), n_db, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+            ctx.synchronize()
+            ctx.profile(True)
+            ctx.profile_reset()
+            t0 = time.perf_counter()
+            for _ in range(launches):
+                ctx.match_device(q.data_ptr(), nq, db.data_ptr(), n_db, idx.data_ptr(), d1.data_ptr(), d2.data_ptr())
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / launches
+            st = ctx.stats()
+            ctx.profile(False)
+            ks = next(s for s in st if s["name"] == "match_stream_kernel")
+            mg = next(s for s in st if s["name"] == "match_stream_merge")
+            gbs = ks["algorithmic_bytes"] / (ks["mean_ms"] * 1e-3) / 1e9
+            both = ks["mean_ms"] + mg["mean_ms"]
+            out[f"{nq}q"] = {"kernel_ms": round(ks["mean_ms"], 4), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                             "merge_launch_ms": round(mg["mean_ms"], 4), "with_merge_GBps": round(ks["algorithmic_bytes"] / (both * 1e-3) / 1e9, 1),
+                             "host_wall_ms_per_query_batch": round(wall * 1e3, 4), "launches": ks["launches"]}
+    del db
+    best = max(out.values(), key=lambda v: v["achieved_GBps"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("k_match_stream@20M_rows")
+    return {"kernel": "k_match_stream (lane = database row, queries in SGPRs)", "bound": "hbm", "achieved": best["achieved_GBps"],
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"], "traffic": traffic,
+            "algorithmic_bytes_per_launch": n_db * 32, "database": "20 000 000 descriptors x 32 B = 640 MB", "by_queries": out}
+
+
+def bench_host_pipeline(binding, frames_sets, w, h, nf, B, local_rank, depth=4, batches=24):
+    """Host frames in, host keypoints / descriptors / matches out through ss_pipe_*: pinned ring of `depth` slots,
+    H2D copy, kernels and D2H copy of different batches overlapped.  Two producers: (a) ss_pipe_submit_frames gathers
+    the caller's pageable frames into the pinned slot with host threads; (b) the producer writes pinned slots itself
+    (acquire / submit: the slots already hold frames; models a decoder or socket that fills pinned memory)."""
+    n_sets = frames_sets.shape[0]
+    res = {}
+    cores = len(os.sched_getaffinity(0))
+    with binding.Pipe(local_rank, w, h, batch=B, depth=depth, match_mode=0, copy_threads=min(8, max(2, cores // 2)), n_features=nf) as pipe:
+        kcap = None
+
+        def drain_one():
+            nonlocal kcap
+            r = pipe.wait()
+            kcap = r["kp_capacity"]
+            ok = int((r["status"] == 0).sum())
+            nk = int(r["n_keypoints"].sum())
+            pipe.release(r["slot"])
+            return ok, nk
+        for mode in ("submit_frames", "pinned_producer"):
+            if mode == "pinned_producer":  # leave real frames in every slot
+                slots = []
+                for s in range(depth):
+                    sl = pipe.acquire()
+                    sl[1][:B, :, :w] = frames_sets[s % n_sets]
+                    slots.append(sl[0])
+                for s in slots:
+                    pipe.release(s)
+            # warm-up
+            for i in range(depth):
+                if mode == "submit_frames":
+                    assert pipe.submit_batch_array(frames_sets[i % n_sets])
+                else:
+                    pipe.submit(pipe.acquire()[0], B)
+            for _ in range(depth):
+                drain_one()
+            done = frames_ok = kps = 0
+            t0 = time.perf_counter()
+            for i in range(batches):
+                if pipe.in_flight() == depth:
+                    ok, nk = drain_one()
+                    frames_ok += ok
+                    kps += nk
+                    done += 1
+                if mode == "submit_frames":
+                    assert pipe.submit_batch_array(frames_sets[i % n_sets])
+                else:
+                    pipe.submit(pipe.acquire()[0], B)
+            while pipe.in_flight():
+                ok, nk = drain_one()
+                frames_ok += ok
+                kps += nk
+                done += 1
+            el = time.perf_counter() - t0
+            assert done == batches and frames_ok == batches * B
+            h2d = batches * B * w * h
+            d2h = batches * B * (kcap * (24 + 32 + 8) + 4 * 18)
+            res[mode] = {"frames_per_s": round(batches * B / el, 1), "pcie_h2d_GBps": round(h2d / el / 1e9, 2),
+                         "pcie_d2h_GBps": round(d2h / el / 1e9, 2), "batches": batches, "mean_keypoints_per_frame": round(kps / (batches * B), 1)}
+    return {"batch": B, "depth": depth, "match": "self-match on the device, results copied back",
+            "frames_per_s": res["submit_frames"]["frames_per_s"], "pcie_GBps": round(res["submit_frames"]["pcie_h2d_GBps"] + res["submit_frames"]["pcie_d2h_GBps"], 2),
+            "submit_frames": res["submit_frames"], "pinned_producer": res["pinned_producer"],
+            "note": "submit_frames = pageable caller frames gathered into the pinned slot by host threads, then H2D; pinned_producer = frames already in the "
+                    "pinned slot (PCIe + kernels only)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 600 for the metric workload, 20 for the others)")
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0, help="frames per step (default 64; stereo 16)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--contexts", type=int, default=4, help="camera batches in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
-                    help="only warm-up + timed steps: no isolated pass, latency or tracking extras (what the rocprofv3 "
-                         "--stats runs use, so every launch they average is a full-batch launch of the timed loop)")
-    ap.add_argument("--workload", default="extract_match", choices=["extract_match", "loop_closure"],
-                    help="extract_match = the BASELINE.json metric (default); loop_closure = config 5: one 2000-descriptor "
-                         "query against a 10 000-keyframe descriptor database sharded over the ranks (strong scaling)")
+                    help="only warm-up + timed steps: no isolated pass, database-streaming, host-pipeline, latency or tracking "
+                         "extras (what the rocprofv3 --stats runs use, so every launch they average is a launch of the timed loop)")
+    ap.add_argument("--profile-extra", default="", choices=["", "match_stream"],
+                    help="run ONLY that extra leg (for rocprofv3 of the database-streaming kernel)")
+    ap.add_argument("--workload", default="extract_match", choices=["extract_match", "loop_closure", "stereo"],
+                    help="extract_match = the BASELINE.json metric (default); stereo = config 4 (2 ranks); loop_closure = config 5: one "
+                         "2000-descriptor query against a 10 000-keyframe descriptor database sharded over the ranks (strong scaling)")
     a = ap.parse_args()
     if a.workload == "loop_closure":
         return bench_loop_closure(a)
+    if a.workload == "stereo":
+        return bench_stereo(a)
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    w, h, nf, B = a.width, a.height, a.features, a.batch
+    w, h, nf = a.width, a.height, a.features
+    B = a.batch or 64
+    steps = a.steps or 600
+    n_ctx = max(1, a.contexts)
+    n_sets = max(2, -(-(CACHE_BYTES + (64 << 20)) // (B * w * h)))  # rotating device batches exceed the Infinity Cache
+    n_sets = -(-n_sets // n_ctx) * n_ctx if n_sets > n_ctx else n_sets  # every context then meets several sets
 
-    frames = make_frames(rank, B, w, h)
+    if a.profile_extra == "match_stream":
+        import torch
+        from send_slam_amd import binding
+        rank, local_rank, dev, backend = dist_setup(world)
+        print(json.dumps({"match_stream_roofline": bench_match_stream(binding, torch, dev, local_rank)}))
+        return
+
+    frames = make_frames(rank, n_sets, B, w, h)
 
     cpu_obj, cpu_outs = None, []
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
-        cpu_obj, cpu_outs = cpu_baseline(frames, nf)  # before any HIP call in this process
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline and not a.profile_extra:
+        cpu_obj, cpu_outs = cpu_baseline(frames[0], nf)  # before any HIP call in this process
 
     import torch
     import torch.distributed as dist
     from send_slam_amd import binding
-
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # rehearsal hooks for a ONE-GPU box (tests / gpurun): SENDSLAM_BENCH_BACKEND=gloo moves the two
-    # timing collectives to the CPU, SENDSLAM_BENCH_ONE_DEVICE=1 puts every rank on device 0.
-    backend = os.environ.get("SENDSLAM_BENCH_BACKEND", "nccl")
-    if os.environ.get("SENDSLAM_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            dist.init_process_group(backend)
+    rank, local_rank, dev, backend = dist_setup(world)
 
     # A few camera batches in flight per GPU: step i runs on context i % n (own stream, own HBM
     # buffers), so the latency-bound quadtree of one batch overlaps the dense kernels of the others.
-    n_ctx = max(1, a.contexts)
     ctxs = [binding.OrbContext(local_rank, n_features=nf, max_batch=B) for _ in range(n_ctx)]
     ctx = ctxs[0]
-    d_frames = torch.from_numpy(frames).to(dev)
+    d_sets = [torch.from_numpy(frames[s]).to(dev) for s in range(n_sets)]
     torch.cuda.synchronize()
 
     # shape the outputs once (kp_capacity is known after the first extraction)
-    ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+    ctx.extract_batch_device(d_sets[0].data_ptr(), B, w, h)
     ctx.synchronize()
-    view = ctx.batch_view()
-    kcap = view.kp_capacity
+    kcap = ctx.batch_view().kp_capacity
     outs = [(torch.empty((B, kcap), dtype=torch.int32, device=dev), torch.empty((B, kcap), dtype=torch.int16, device=dev),
              torch.empty((B, kcap), dtype=torch.int16, device=dev)) for _ in range(n_ctx)]
-    d_idx = outs[0][0]
+    last_set = [0] * n_ctx
 
     def step(i):
-        c, (o_idx, o_d1, o_d2) = ctxs[i % n_ctx], outs[i % n_ctx]
-        c.extract_batch_device(d_frames.data_ptr(), B, w, h)
+        k = i % n_ctx
+        c, (o_idx, o_d1, o_d2) = ctxs[k], outs[k]
+        last_set[k] = i % n_sets
+        c.extract_batch_device(d_sets[i % n_sets].data_ptr(), B, w, h)
         c.match_batch_device(0, o_idx.data_ptr(), o_d1.data_ptr(), o_d2.data_ptr())
 
     for i in range(max(a.warmup, n_ctx)):
@@ -233,73 +511,131 @@ def main():
     for c in ctxs:
         c.synchronize()
 
+    # rate of each 1/25th of the timed region, from events recorded on the contexts' streams (no drain in between)
+    n_chunks = 25 if steps >= 100 else 0
+    chunk_ev = []
+    ext = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs]
+
+    def mark():
+        evs = []
+        for s_ in ext:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(s_)
+            evs.append(e)
+        chunk_ev.append(evs)
+
+    # per-kernel HIP events on each context's own stream, live over the timed region (SENDSLAM_BENCH_NO_EVENTS=1
+    # switches them off to measure what they cost)
+    live_events = os.environ.get("SENDSLAM_BENCH_NO_EVENTS") != "1"
     for c in ctxs:
-        c.profile(True)
+        c.profile(live_events)
         c.profile_reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
+    if n_chunks:
+        bounds = [round(steps * j / n_chunks) for j in range(n_chunks + 1)]
+        mark()
+        for j in range(n_chunks):
+            for i in range(bounds[j], bounds[j + 1]):
+                step(i)
+            mark()
+    else:
+        for i in range(steps):
+            step(i)
     for c in ctxs:
         c.synchronize()  # drains the context's stream and checks the per-frame error words
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, dev, backend)
+
+    spread = None
+    if n_chunks:
+        rates = []
+        for j in range(n_chunks):
+            # chunk j = from the latest of the start marks to the latest of the end marks over the contexts
+            ref = chunk_ev[0][0]
+            t_start = max(ref.elapsed_time(e) for e in chunk_ev[j])
+            t_end = max(ref.elapsed_time(e) for e in chunk_ev[j + 1])
+            n_fr = (bounds[j + 1] - bounds[j]) * B
+            if t_end > t_start:
+                rates.append(n_fr / ((t_end - t_start) * 1e-3))
+        rates.sort()
+        if rates:
+            spread = {"chunks": len(rates), "steps_per_chunk": steps // n_chunks, "median": round(rates[len(rates) // 2], 1),
+                      "min": round(rates[0], 1), "max": round(rates[-1], 1), "unit": "frames/s per rank"}
+
+    # per-kernel HIP-event statistics of the timed loop (summed over the contexts)
+    def merged_stats(cs):
+        stats = []
+        for c in cs:
+            for s_ in c.stats():
+                m = next((x for x in stats if x["name"] == s_["name"]), None)
+                if m is None:
+                    stats.append(dict(s_))
+                else:
+                    tot = m["total_ms"] + s_["total_ms"]
+                    n_l = m["launches"] + s_["launches"]
+                    m.update(total_ms=tot, launches=n_l, mean_ms=tot / n_l if n_l else 0.0)
+        return stats
+    stats = merged_stats(ctxs)
     for c in ctxs:
         c.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
-    # per-kernel HIP-event statistics, summed over the contexts
-    stats = []
-    for c in ctxs:
-        for s_ in c.stats():
-            m = next((x for x in stats if x["name"] == s_["name"]), None)
-            if m is None:
-                stats.append(dict(s_))
-            else:
-                tot = m["total_ms"] + s_["total_ms"]
-                n_l = m["launches"] + s_["launches"]
-                m.update(total_ms=tot, launches=n_l, mean_ms=tot / n_l if n_l else 0.0)
-
-    # The timed region keeps two batches in flight, so a kernel's live duration includes the other
-    # stream's kernels sharing the chip.  A short extra pass on ONE context gives each kernel's
-    # duration when it has the GPU to itself (reported next to the live number, never instead).
-    iso = {}
-    ctx.profile(True)
-    ctx.profile_reset()
-    for _ in range(0 if a.timed_only else 5):
-        ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
-        ctx.match_batch_device(0, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
-        ctx.synchronize()
-    for s_ in ctx.stats():
-        iso[s_["name"]] = s_["mean_ms"]
-    ctx.profile(False)
-
-    # parity spot-check of the measured configuration against the oracle outputs of the baseline leg
+    # parity of the measured configuration: EVERY context's last timed batch against the oracle (frame 1 + its own
+    # index of that batch: the oracle costs 0.1 s per frame), then all frames of the baseline leg on context 0
     parity = None
-    if cpu_outs:
-        idx = d_idx.cpu().numpy()
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle import orb_oracle as O
         parity = True
-        for b, (okps, odesc, oidx, od1, od2) in enumerate(cpu_outs):
-            kps_b, desc_b, _ = ctx.fetch_frame(b)
-            n = len(kps_b)
-            parity &= n == len(okps) and kps_b.tobytes() == okps.tobytes()
-            parity &= bool(np.array_equal(desc_b, odesc)) and bool(np.array_equal(idx[b, :n], oidx))
+        p = O.default_params(n_features=nf)
+        for k, c in enumerate(ctxs):
+            idx = outs[k][0].cpu().numpy()
+            for b in sorted({1 % B, (7 * k + 3) % B}):
+                okps, odesc, _ = O.extract(frames[last_set[k], b], p)
+                oidx, _, _ = O.match(odesc, odesc, 50, 9, 10, exclude_self=True)
+                kps_b, desc_b, _ = c.fetch_frame(b)
+                n = len(kps_b)
+                parity &= n == len(okps) and kps_b.tobytes() == okps.tobytes()
+                parity &= bool(np.array_equal(desc_b, odesc)) and bool(np.array_equal(idx[b, :n], oidx))
+        if cpu_outs:
+            ctx.extract_batch_device(d_sets[0].data_ptr(), B, w, h)
+            ctx.match_batch_device(0, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+            ctx.synchronize()
+            idx = outs[0][0].cpu().numpy()
+            for b, (okps, odesc, oidx, od1, od2) in enumerate(cpu_outs):
+                kps_b, desc_b, _ = ctx.fetch_frame(b)
+                n = len(kps_b)
+                parity &= n == len(okps) and kps_b.tobytes() == okps.tobytes()
+                parity &= bool(np.array_equal(desc_b, odesc)) and bool(np.array_equal(idx[b, :n], oidx))
         if not parity:
             sys.exit("bench.py: GPU results differ from the oracle on the benchmark frames")
+
+    # The timed region keeps several batches in flight, so a kernel's live event pair also counts the time it waits
+    # for its turn next to the other streams' kernels.  A short extra pass on ONE context gives each kernel's duration
+    # when it has the GPU to itself -- the number rocprofv3's kernel trace reports for the same kernel -- reported next
+    # to the live number, never instead.
+    iso = {}
+    if not a.timed_only:
+        ctx.profile(True)
+        ctx.profile_reset()
+        for i in range(2 * n_sets):
+            ctx.extract_batch_device(d_sets[i % n_sets].data_ptr(), B, w, h)
+            ctx.match_batch_device(0, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+            ctx.synchronize()
+        for s_ in ctx.stats():
+            iso[s_["name"]] = s_["mean_ms"]
+        ctx.profile(False)
 
     # Latency path of the drop-in boundary (what the NIF / front door call per camera frame):
     # host pixels in, host keypoints + descriptors out, PCIe copies included.  Never `value`.
     lat = []
     for i in range(0 if a.timed_only else 12):
         t1 = time.perf_counter()
-        ctx.extract(frames[i % B])
+        ctx.extract(frames[0, i % B])
         lat.append(time.perf_counter() - t1)
     lat = sorted(lat[2:])
     single_frame_ms = lat[len(lat) // 2] * 1e3 if lat else None
@@ -326,6 +662,18 @@ def main():
             tl.sort()
             track_ms, track_ok = tl[len(tl) // 2] * 1e3, states.count(2)
 
+    for c in ctxs:
+        c.close()
+    del d_sets, outs
+
+    match_stream = host_pipe = None
+    if rank == 0 and not a.timed_only:
+        torch.cuda.empty_cache()
+        match_stream = bench_match_stream(binding, torch, dev, local_rank)
+        torch.cuda.empty_cache()
+        if world == 1:
+            host_pipe = bench_host_pipeline(binding, frames, w, h, nf, B, local_rank)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -337,33 +685,32 @@ def main():
             continue
         gbs = s["algorithmic_bytes"] / (s["mean_ms"] * 1e-3) / 1e9 if s["mean_ms"] > 0 and s["algorithmic_bytes"] else None
         im = iso.get(s["name"])
-        kernels.append({"name": s["name"], "launches_per_step": s["launches"] / a.steps, "mean_ms": round(s["mean_ms"], 5),
-                        "total_ms": round(s["total_ms"], 3), "algorithmic_bytes_per_launch": s["algorithmic_bytes"],
+        kernels.append({"name": s["name"], "launches": s["launches"], "mean_ms": round(s["mean_ms"], 5),
+                        "algorithmic_bytes_per_launch": s["algorithmic_bytes"],
                         "achieved_GBps": None if gbs is None else round(gbs, 1),
                         "isolated_mean_ms": None if not im else round(im, 5),
                         "isolated_GBps": None if not im or not s["algorithmic_bytes"] else round(s["algorithmic_bytes"] / (im * 1e-3) / 1e9, 1)})
     with_bytes = [k for k in kernels if k["achieved_GBps"] is not None]
-    dom = max(with_bytes, key=lambda k: k["total_ms"]) if with_bytes else None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if dom and os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        key = f"{dom['name']}@batch{B}_{w}x{h}_n{nf}"
-        traffic = tj.get(key)
+    dom = max(with_bytes, key=lambda k: (k["isolated_mean_ms"] or k["mean_ms"]) * k["launches"]) if with_bytes else None
+    stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match_mfma", "orient_describe": "k_orient_describe", "resize": "k_resize_lds"}
+    prof = {}
+    ppath = os.path.join(ROOT, "profiles", "per_frame_counters.json")
+    if os.path.exists(ppath):
+        prof = json.load(open(ppath)).get(f"{w}x{h}_n{nf}", {})
     roofline = None
     if dom:
-        # `achieved` uses the kernel's duration with one batch in flight (HIP events on the launch stream, the
-        # pass above): that is the number rocprofv3's kernel trace reports for the same kernel (profiles/
-        # r01_bench_kernel_stats*.csv: 419 us alone, 442 us while the other batches' kernels share the chip).  HIP
-        # events recorded while several streams are in flight also count the time a kernel waits for its turn, so the
-        # timed-region event mean is reported separately and is not a kernel duration.
+        # `achieved` uses the kernel's duration with one batch in flight (HIP events on the launch stream): that is
+        # the number rocprofv3's kernel trace reports for the same kernel (profiles/).  HIP events recorded while
+        # several streams are in flight also count the time a kernel waits for its turn, so the live event mean is
+        # reported separately and is not a kernel duration.
         ach = dom["isolated_GBps"] if dom["isolated_GBps"] else dom["achieved_GBps"]
+        per_frame = prof.get(stage_kernel.get(dom["name"], ""), {}).get("hbm_bytes_per_frame")
         roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None if per_frame is None else int(per_frame * B),
                     "kernel_ms": dom["isolated_mean_ms"] if dom["isolated_GBps"] else dom["mean_ms"],
-                    "timed_region_event_ms": dom["mean_ms"], "timed_region_event_GBps": dom["achieved_GBps"],
-                    "note": "integer-VALU-bound kernel (DESIGN.md section 5: 86 % of the measured VALU issue rate): the HBM "
-                            "fraction is reported because the contract asks for it, not because HBM limits it"}
+                    "live_event_ms": dom["mean_ms"], "live_event_GBps": dom["achieved_GBps"],
+                    "note": "integer-VALU-bound kernel (DESIGN.md section 5): the HBM fraction is reported because the contract "
+                            "asks for it, not because HBM limits it; see valu_roofline"}
 
     # the Hamming-match kernel (k_match_mfma) against the two pipes it uses: the distance of a
     # (query, train) pair is a 256-term i8 contraction on the matrix cores (512 int8 ops), the best / second-best
@@ -386,35 +733,38 @@ def main():
                           "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
                           "kernel_ms": mk["isolated_mean_ms"], "mfma_floor_ms": round(mfma_floor_ms, 4),
                           "valu_select_cycles_per_64_pairs": round(sel, 1), "valu_select_floor_ms": round(valu_floor_ms, 4),
-                          "frac_of_the_larger_floor": round(max(valu_floor_ms, mfma_floor_ms) / mk["isolated_mean_ms"], 4),
                           "pairs_per_s": float(f"{pairs / t:.4g}")}
 
-    # the dominant kernel against the resource that bounds it: VALU issue.  Instruction count per launch from the
-    # committed PMC pass of this workload (profiles/r01_pmc_sq_mix.json, SQ_INSTS_VALU of a full-batch launch),
-    # duration live; peak = the measured issue rate (profiles/r01_peaks.json).
+    # the dominant kernel against the resource that bounds it: VALU issue.  Instructions per FRAME from the committed
+    # PMC pass (profiles/per_frame_counters.json: SQ_INSTS_VALU of full-batch launches / frames), duration live; peak =
+    # the measured issue rate (profiles/r01_peaks.json).
     valu_roofline = None
-    ppath = os.path.join(ROOT, "profiles", "r01_peaks.json")
-    mix_path = os.path.join(ROOT, "profiles", "r01_pmc_sq_mix.json")
-    if dom and dom.get("isolated_mean_ms") and os.path.exists(mix_path) and os.path.exists(ppath) and (B, w, h, nf) == (64, 1280, 720, 2000):
-        stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match", "orient_describe": "k_orient_describe"}.get(dom["name"])
-        insts = json.load(open(mix_path)).get(stage_kernel, {}).get("SQ_INSTS_VALU")
+    pk_path = os.path.join(ROOT, "profiles", "r01_peaks.json")
+    if dom and dom.get("isolated_mean_ms") and os.path.exists(pk_path):
+        insts = prof.get(stage_kernel.get(dom["name"], ""), {}).get("valu_wave_insts_per_frame")
         if insts:
-            peak = json.load(open(ppath))["xor_popc_lane_ops_per_s"]
-            ach = insts * 64 / (dom["isolated_mean_ms"] * 1e-3)
+            peak = json.load(open(pk_path))["xor_popc_lane_ops_per_s"]
+            ach = insts * B * 64 / (dom["isolated_mean_ms"] * 1e-3)
             valu_roofline = {"kernel": dom["name"], "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
-                             "unit": "lane-ops/s", "frac": round(ach / peak, 4), "valu_wave_instructions_per_launch": insts}
+                             "unit": "lane-ops/s", "frac": round(ach / peak, 4), "valu_wave_instructions_per_launch": int(insts * B)}
 
-    total_frames = B * a.steps * world
+    total_frames = B * steps * world
     out = {
         "metric": "frames/sec ORB extract+match @1280x720, 2000 kp/frame",
-        "value": round(total_frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+        "value": round(total_frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": steps,
+        "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"{world}xMI355X: synthetic {w}x{h} frames, ORB extract + self-match, {nf} kp/frame",
-                   "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx, "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
+                   "frames_per_step_per_gpu": B, "batches_in_flight_per_gpu": n_ctx,
+                   "distinct_device_batches_rotated": n_sets, "device_frame_set_bytes": int(n_sets * B * w * h),
+                   "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
-        "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline, "kernels": kernels, "cpu_baseline": cpu_obj, "parity_checked_vs_oracle": parity,
+        "timed_region_s": round(elapsed, 4), "value_spread": spread,
+        "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline,
+        "match_stream_roofline": match_stream, "host_pipeline": host_pipe, "kernels": kernels, "cpu_baseline": cpu_obj,
+        "parity_checked_vs_oracle": parity,
+        "parity_note": "oracle = the committed CPU restatement; parity with the real ORB-SLAM3 binary is unpinned (DESIGN.md section 3)",
         "single_frame_host_to_host_ms": None if single_frame_ms is None else round(single_frame_ms, 3),
         "track_frame_host_to_host_ms": None if track_ms is None else round(track_ms, 3), "track_ok_frames_of_14": track_ok,
     }

@@ -185,6 +185,14 @@ int ss_match_device(ss_ctx *ctx, const void *d_query, int n_query, const void *d
 int ss_match_batch_device(ss_ctx *ctx, int mode, int th, int ratio_num, int ratio_den,
                           void *d_idx, void *d_d1, void *d_d2);
 
+/* n_frames independent (query frame, train frame) pairs in one launch, e.g. the frames of this GPU's eye against the
+ * all-gathered frames of the peer eye.  Both sides are device arrays
+ * [n_frames][rows_per_frame][32] with per-frame row counts d_n_query / d_n_train (device int32 [n_frames]); outputs
+ * are [n_frames][rows_per_frame], rows >= n_query[b] get idx -1 / 0xFFFF.  No self-exclusion. */
+int ss_match_pairs_device(ss_ctx *ctx, const void *d_query, const void *d_n_query, const void *d_train,
+                          const void *d_n_train, int n_frames, int rows_per_frame, int th, int ratio_num,
+                          int ratio_den, void *d_idx, void *d_d1, void *d_d2);
+
 /* Pose of one frame (shim :225-282 SendPosePacket: position + quaternion x y z w of Twc, shipped
  * only in tracking state OK :596).  tracking_state uses ORB_SLAM3::Tracking::eTrackingState values:
  * 0 NO_IMAGES_YET, 1 NOT_INITIALIZED, 2 OK, 4 LOST. */

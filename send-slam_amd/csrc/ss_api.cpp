@@ -559,9 +559,18 @@ int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_t
         /* a handful of queries against a large database: stream the database once (HBM-bound) */
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)SSK_STREAM_PARTIAL_MAX);
         if (rc != SS_OK) return rc;
-        stage_timer t(c, "match_stream", (int64_t)n_query * 32 + (int64_t)n_train * 32 + (int64_t)n_query * 8);
-        if (ssk_match_stream(c->stream, d_query, d_train, n_query, n_train, th, ratio_num, ratio_den, c->match_partial,
-                             c->match_partial_bytes, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2)) {
+        int s_len = 0, s_chunks = 0;
+        if (ssk_match_stream_plan(n_query, n_train, c->match_partial_bytes, &s_len, &s_chunks)) {
+            {
+                /* the kernel that reads the database exactly once: timed on its own (bench.py match_stream_roofline) */
+                stage_timer t(c, "match_stream_kernel", (int64_t)n_query * 32 + (int64_t)n_train * 32 + (int64_t)s_chunks * n_query * 8);
+                ssk_match_stream_kernel(c->stream, d_query, d_train, n_query, n_train, s_len, s_chunks, c->match_partial);
+            }
+            {
+                stage_timer t(c, "match_stream_merge", (int64_t)s_chunks * n_query * 8 + (int64_t)n_query * 8);
+                ssk_match_stream_merge(c->stream, c->match_partial, n_query, s_chunks, th, ratio_num, ratio_den, (int32_t *)d_idx,
+                                       (uint16_t *)d_d1, (uint16_t *)d_d2);
+            }
             HIP_TRY(c, hipGetLastError());
             return SS_OK;
         }
@@ -626,6 +635,31 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
         ssk_match(c->stream, c->desc, c->desc, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 8, (int64_t)kcap * 8,
                   mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
                   c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query, const void *d_train, const void *d_n_train,
+                          int n_frames, int rows_per_frame, int th, int ratio_num, int ratio_den, void *d_idx, void *d_d1,
+                          void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_frames < 0 || rows_per_frame < 1 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
+    if (n_frames == 0) return SS_OK;
+    if (!d_query || !d_n_query || !d_train || !d_n_train || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    int chunk_len = 4;
+    const int n_chunks = ssk_match_chunks(rows_per_frame, rows_per_frame, n_frames, &chunk_len);
+    if (n_chunks > 1) {
+        int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_frames * n_chunks * rows_per_frame * SSK_MATCH_PARTIAL_BYTES);
+        if (rc != SS_OK) return rc;
+    }
+    {
+        stage_timer t(c, "match", (int64_t)n_frames * rows_per_frame * (32 * 2 + 8));
+        ssk_match(c->stream, d_query, d_train, (const int32_t *)d_n_query, (const int32_t *)d_n_train, 0, rows_per_frame,
+                  (int64_t)rows_per_frame * 8, (int64_t)rows_per_frame * 8, 0, chunk_len, n_chunks, 0, th, ratio_num, ratio_den,
+                  rows_per_frame, c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n_frames);
     }
     HIP_TRY(c, hipGetLastError());
     return SS_OK;

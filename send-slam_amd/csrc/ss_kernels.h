@@ -57,9 +57,13 @@ void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int t
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8
 #define SSK_MATCH_MFMA_MIN_QUERIES 128 /* from this many query rows on, ssk_match runs the matrix-core kernel */
-/* database-streaming form for n_query <= 8 and n_train >= 65536; false = not applicable */
-bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,
-                      void *partial, size_t partial_bytes, int32_t *idx, uint16_t *d1, uint16_t *d2);
+/* database-streaming form for n_query <= 8 and n_train >= 65536: plan (false = not applicable), the HBM-bound kernel,
+ * the merge of its per-chunk partials */
+bool ssk_match_stream_plan(int nq, int nt, size_t partial_bytes, int *chunk_len, int *n_chunks);
+void ssk_match_stream_kernel(hipStream_t s, const void *query, const void *train, int nq, int nt, int chunk_len, int n_chunks,
+                             void *partial);
+void ssk_match_stream_merge(hipStream_t s, const void *partial, int nq, int n_chunks, int th, int rnum, int rden, int32_t *idx,
+                            uint16_t *d1, uint16_t *d2);
 #define SSK_STREAM_PARTIAL_MAX (2048 * 8 * SSK_MATCH_PARTIAL_BYTES)
 
 #endif

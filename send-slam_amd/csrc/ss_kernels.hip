@@ -2181,9 +2181,9 @@ void ssk_match(hipStream_t s, const void *query, const void *train, const int32_
     }
 }
 
-/* database-streaming match for n_query <= 8 (see k_match_stream); returns false if not applicable */
-bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int nq, int nt, int th, int rnum, int rden,
-                      void *partial, size_t partial_bytes, int32_t *idx, uint16_t *d1, uint16_t *d2)
+/* database-streaming match for n_query <= 8 (see k_match_stream): plan (false = not applicable), kernel launch, merge
+ * launch -- separate calls so that the caller can time the HBM-bound kernel on its own */
+bool ssk_match_stream_plan(int nq, int nt, size_t partial_bytes, int *chunk_len_out, int *n_chunks_out)
 {
     if (nq < 1 || nq > 8 || nt < 65536) return false;
     int n_chunks = 256 * 8;                       /* 8 resident blocks per CU */
@@ -2192,6 +2192,14 @@ bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int n
     if (chunk_len > (1 << 22) * 256 / 256) return false;
     n_chunks = (nt + chunk_len - 1) / chunk_len;
     if ((size_t)n_chunks * nq * SSK_MATCH_PARTIAL_BYTES > partial_bytes) return false;
+    *chunk_len_out = chunk_len;
+    *n_chunks_out = n_chunks;
+    return true;
+}
+
+void ssk_match_stream_kernel(hipStream_t s, const void *query, const void *train, int nq, int nt, int chunk_len, int n_chunks,
+                             void *partial)
+{
     const uint32_t *q = (const uint32_t *)query;
     const uint4 *t = (const uint4 *)train;
     match_partial *p = (match_partial *)partial;
@@ -2199,9 +2207,13 @@ bool ssk_match_stream(hipStream_t s, const void *query, const void *train, int n
     else if (nq == 2) hipLaunchKernelGGL(k_match_stream<2>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
     else if (nq <= 4) hipLaunchKernelGGL(k_match_stream<4>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
     else hipLaunchKernelGGL(k_match_stream<8>, dim3(n_chunks), dim3(256), 0, s, q, t, nq, nt, chunk_len, n_chunks, p);
+}
+
+void ssk_match_stream_merge(hipStream_t s, const void *partial, int nq, int n_chunks, int th, int rnum, int rden, int32_t *idx,
+                            uint16_t *d1, uint16_t *d2)
+{
     hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
                        idx, d1, d2);
-    return true;
 }
 
 void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, const uint16_t *d2, int n, int32_t row_offset,

@@ -18,15 +18,39 @@ link: README.md:5, application.ex:80); the three shapes come from BASELINE.json'
 All messages are <= 64 KB per rank: latency-bound on xGMI, so one all_gather per exchange and
 no bucketing.  The fold is the same rule the match kernel uses across its train chunks
 (csrc/ss_kernels.hip merge_partial).
+
+On the GPU the whole query is three launches behind the C ABI and no torch arithmetic:
+ss_match_partial_device (raw local match -> 8-byte records with global rows), one all_gather of
+N x nq x 8 B, ss_match_fold_device (k_match_merge over the gathered records + acceptance test).
+Stream order: every torch / RCCL call of a query runs with the context's own HIP stream as torch's
+current stream (`on_ctx_stream`), so collectives and kernels are ordered by the stream itself and
+nothing is matched before the broadcast / all_gather that produces it has landed.  The torch
+functions `fold_partials` / `accept` remain as the CPU rehearsal of the same rule (gloo tests) and as
+the checker of the fold kernel.
 """
 from __future__ import annotations
 
 from typing import Callable, List, Sequence, Tuple
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
 NONE = 0xFFFF
+
+
+@contextlib.contextmanager
+def on_ctx_stream(ctx, device=None):
+    """Makes the context's HIP stream torch's current stream: torch kernels, RCCL collectives and the
+    library's own launches are then ordered by ONE stream (a collective enqueued here waits for what the
+    stream holds, and what is enqueued after it waits for the collective)."""
+    if ctx is None or not torch.cuda.is_available():
+        yield None
+        return
+    ext = torch.cuda.ExternalStream(ctx.stream(), device=device)
+    with torch.cuda.stream(ext):
+        yield ext
 
 
 def shard_cameras(n_cameras: int, world: int, rank: int) -> List[int]:
@@ -78,17 +102,59 @@ LocalMatch = Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Te
 
 def hip_local_match(ctx) -> LocalMatch:
     """Raw (th < 0) ss_match_device on this rank's GPU: (query u8[nq,32], train u8[nt,32]) device
-    tensors -> (j1 int32, d1, d2 as int32) device tensors."""
+    tensors -> (j1 int32, d1, d2 as int32) device tensors.  The inputs may have been produced on torch's
+    current stream (a collective's output): the context's stream is ordered after it first."""
     def run(q: torch.Tensor, t: torch.Tensor):
         nq, nt = q.shape[0], t.shape[0]
         idx = torch.empty(nq, dtype=torch.int32, device=q.device)
         d1 = torch.empty(nq, dtype=torch.int16, device=q.device)
         d2 = torch.empty(nq, dtype=torch.int16, device=q.device)
+        ctx.wait_stream(torch.cuda.current_stream(q.device).cuda_stream)
         ctx.match_device(q.data_ptr(), nq, t.data_ptr() if nt else 0, nt, idx.data_ptr(), d1.data_ptr(),
                          d2.data_ptr(), th=-1)
         ctx.synchronize()
         return idx, d1.to(torch.int32) & 0xFFFF, d2.to(torch.int32) & 0xFFFF
+    run.ctx = ctx
     return run
+
+
+def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, th: int = 50,
+                              ratio_num: int = 9, ratio_den: int = 10, src: int = 0, out=None):
+    """Config 5 on the GPUs, behind the C ABI: broadcast -> ss_match_partial_device -> all_gather of
+    world x nq x 8 B -> ss_match_fold_device, all on the context's stream (no host synchronisation inside;
+    the caller synchronises when it reads the result).  Returns device tensors (idx i32, d1 i16, d2 i16:
+    the 16-bit distances, 0xFFFF = none)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    nq, dev = query.shape[0], query.device
+    with on_ctx_stream(ctx, dev):
+        if world > 1:
+            if dist.get_backend() == "gloo":
+                q = query.cpu()
+                dist.broadcast(q, src=src)
+                query = q.to(dev)
+            else:
+                dist.broadcast(query, src=src)
+        part = torch.empty(nq, dtype=torch.int64, device=dev)  # nq x ss_match_part (8 B)
+        nt = db_slab.shape[0]
+        ctx.match_partial_device(query.data_ptr(), nq, db_slab.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+        if world > 1:
+            if dist.get_backend() == "gloo":
+                ctx.synchronize()
+                src_t = part.cpu()
+                outs = [torch.empty_like(src_t) for _ in range(world)]
+                dist.all_gather(outs, src_t)
+                parts = torch.stack(outs).to(dev)
+            else:
+                parts = torch.empty((world, nq), dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(parts, part)
+        else:
+            parts = part.view(1, nq)
+        if out is None:
+            out = (torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, dtype=torch.int16, device=dev),
+                   torch.empty(nq, dtype=torch.int16, device=dev))
+        ctx.match_fold_device(parts.data_ptr(), world, nq, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                              th=th, ratio_num=ratio_num, ratio_den=ratio_den)
+    return out
 
 
 def loop_closure_query(query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, local_match: LocalMatch,
@@ -114,10 +180,11 @@ def stereo_exchange(desc: torch.Tensor, n_kp: int, local_match: LocalMatch, th: 
     against the peer eye's: (idx into the peer's rows, d1, d2, peer_n_kp)."""
     assert dist.get_world_size() == 2
     rank = dist.get_rank()
-    blocks = all_gather_fixed(desc)
-    counts = all_gather_fixed(torch.tensor([n_kp], dtype=torch.int64, device=desc.device))
-    peer = 1 - rank
-    peer_n = int(counts[peer].item())
+    with on_ctx_stream(getattr(local_match, "ctx", None), desc.device if desc.is_cuda else None):
+        blocks = all_gather_fixed(desc)
+        counts = all_gather_fixed(torch.tensor([n_kp], dtype=torch.int64, device=desc.device))
+        peer = 1 - rank
+        peer_n = int(counts[peer].item())
     j1, d1, d2 = local_match(desc[:n_kp], blocks[peer][:peer_n])
     idx = accept(d1.long(), j1.long(), d2.long(), th, ratio_num, ratio_den).to(torch.int32)
     return idx, d1, d2, peer_n

@@ -67,6 +67,15 @@ def run(rank, world, port, use_gpu, out_dir):
         np.savez(os.path.join(out_dir, f"st_{rank}.npz"), idx=sidx.cpu().numpy(), d1=sd1.cpu().numpy(), d2=sd2.cpu().numpy(),
                  peer_n=peer_n)
         if use_gpu:
+            # the same query through the C-ABI path (partial -> all_gather -> fold kernel), then a DIFFERENT query per
+            # call, each taken from a device tensor on rank 0: a stale query or a stale gathered block would show
+            for k, seed in enumerate((5, 6, 7)):
+                qk, dbk = make_db(seed, 4001, 150)
+                query = torch.from_numpy(qk if rank == 0 else np.zeros_like(qk)).to(dev)
+                idx, d1, d2 = multi.loop_closure_query_device(ctx, query, torch.from_numpy(dbk[b:e]).to(dev), b, th=256, ratio_num=10)
+                ctx.synchronize()
+                np.savez(os.path.join(out_dir, f"lcd{k}_{rank}.npz"), idx=idx.cpu().numpy(), d1=d1.cpu().numpy().view(np.uint16),
+                         d2=d2.cpu().numpy().view(np.uint16))
             ctx.close()
     finally:
         dist.destroy_process_group()

@@ -22,6 +22,15 @@ def free_port():
     return p
 
 
+def check_device_path_outputs(out_dir, oracle):
+    for k, seed in enumerate((5, 6, 7)):
+        q, db = multi_worker.make_db(seed, 4001, 150)
+        want = oracle.match(q, db, th=256, ratio_num=10)
+        for r in range(2):
+            z = np.load(os.path.join(out_dir, f"lcd{k}_{r}.npz"))
+            assert np.array_equal(z["idx"], want[0]) and np.array_equal(z["d1"], want[1]) and np.array_equal(z["d2"], want[2]), (k, r)
+
+
 def check_outputs(out_dir, oracle):
     q, db = multi_worker.make_db(5, 4001, 150)
     want = oracle.match(q, db, th=256, ratio_num=10)
@@ -83,6 +92,37 @@ def test_world2_gloo_two_ranks_one_gpu(tmp_path, oracle):
     port = free_port()
     mp.spawn(multi_worker.run, args=(2, port, True, str(tmp_path)), nprocs=2, join=True)
     check_outputs(str(tmp_path), oracle)
+    check_device_path_outputs(str(tmp_path), oracle)
+
+
+@pytest.mark.gpu
+def test_fold_kernel_equals_torch_fold(oracle):
+    """ss_match_fold_device (one launch of k_match_merge's rule) against multi.fold_partials + accept on random
+    records with many ties and empty shards."""
+    from send_slam_amd import binding
+    rng = np.random.default_rng(8)
+    dev = torch.device("cuda:0")
+    with binding.OrbContext(0) as ctx:
+        for n_parts, nq in ((2, 100), (8, 2000), (5, 1)):
+            d1 = rng.integers(0, 6, size=(n_parts, nq)).astype(np.uint16)
+            d2 = (d1 + rng.integers(0, 3, size=(n_parts, nq))).astype(np.uint16)
+            row = (np.arange(n_parts)[:, None] * 1000 + rng.integers(0, 1000, size=(n_parts, nq))).astype(np.int32)
+            empty = rng.random((n_parts, nq)) < 0.2
+            d1[empty], d2[empty], row[empty] = 0xFFFF, 0xFFFF, -1
+            rec = np.zeros((n_parts, nq), np.dtype([("d1", "<u2"), ("d2", "<u2"), ("row", "<i4")]))
+            rec["d1"], rec["d2"], rec["row"] = d1, d2, row
+            parts = torch.from_numpy(rec.view(np.int64).reshape(n_parts, nq)).to(dev)
+            idx = torch.empty(nq, dtype=torch.int32, device=dev)
+            o1 = torch.empty(nq, dtype=torch.int16, device=dev)
+            o2 = torch.empty(nq, dtype=torch.int16, device=dev)
+            ctx.match_fold_device(parts.data_ptr(), n_parts, nq, idx.data_ptr(), o1.data_ptr(), o2.data_ptr(), th=4, ratio_num=9)
+            ctx.synchronize()
+            t = lambda a: [torch.from_numpy(a[p].astype(np.int64)) for p in range(n_parts)]  # noqa: E731
+            fd1, fj1, fd2 = multi.fold_partials(t(d1), t(row), t(d2))
+            want_idx = multi.accept(fd1, fj1, fd2, th=4, ratio_num=9, ratio_den=10)
+            assert np.array_equal(idx.cpu().numpy(), want_idx.numpy().astype(np.int32))
+            assert np.array_equal(o1.cpu().numpy().view(np.uint16), fd1.numpy().astype(np.uint16))
+            assert np.array_equal(o2.cpu().numpy().view(np.uint16), fd2.numpy().astype(np.uint16))
 
 
 @pytest.mark.gpu
