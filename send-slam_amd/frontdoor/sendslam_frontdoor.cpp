@@ -12,8 +12,8 @@
  *   BuildCalibrationYaml (ORB literals)     :158-223           -> settings_text (for logs) +
  *                                                                 ss_orb_params / ss_camera
  *   main: env, connect, framing, guards     :341-627           -> main
- *   cv::imdecode(IMREAD_UNCHANGED) on PNM   :546               -> decode_pnm (P5 -> 1 channel,
- *                                                                 P6 -> 3 channels in BGR order)
+ *   cv::imdecode(IMREAD_UNCHANGED) on PNM   :546               -> pnm_header + pnm_copy (P5 -> 1
+ *                                                                 channel, P6 -> 3 channels in BGR order)
  *   TrackMonocular                          :594               -> ss_track (HIP extraction + HIP
  *                                                                 match + host geometry; a bounded
  *                                                                 monocular front-end)
@@ -27,12 +27,18 @@
  *                              slam_handler.ex:131-132)
  *   SENDSLAM_ORB_NFEATURES=n   override the 1250 literal (BASELINE.json benches use 2000)
  *   SENDSLAM_DEVICE=k          HIP device ordinal (one backend process per GPU / camera)
+ *   SENDSLAM_NO_PACING=1       no sleep between frames (:618-624 switched off) AND read-ahead: frames already
+ *                              queued on the socket are decoded straight into a pinned slot of an ss_pipe (up to
+ *                              SENDSLAM_READAHEAD per batch, default 16), extracted as one batch while the next
+ *                              ones are received, then tracked in order (ss_track_features): same poses, same
+ *                              messages, in the same order as frame-by-frame ss_track (tests/test_wire.py)
  *   --selftest-pose            print the pose packet for fixed values as hex and exit (golden
  *                              wire bytes, tests/test_wire.py; needs no GPU)
  */
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -166,7 +172,7 @@ string settings_text(const CameraCalibration &c, const ss_orb_params &p)
 /* cv::imdecode(IMREAD_UNCHANGED) for the two encodings the host sends (PPM from
  * Evision.imencode(".ppm"), slam_handler.ex:275-281; PGM for gray frames).  Returns false
  * if the buffer is not a binary 8-bit PNM ("Failed to decode frame image data.", :547-551). */
-bool decode_pnm(const uint8_t *p, size_t n, int &w, int &h, int &channels, vector<uint8_t> &pix)
+bool pnm_header(const uint8_t *p, size_t n, int &w, int &h, int &channels, size_t &data_off)
 {
     size_t i = 0;
     auto token = [&](long &out) -> bool {
@@ -200,15 +206,25 @@ bool decode_pnm(const uint8_t *p, size_t n, int &w, int &h, int &channels, vecto
     if (n - i < need) return false;
     w = (int)lw;
     h = (int)lh;
-    pix.resize(need);
-    if (channels == 1) memcpy(pix.data(), p + i, need);
-    else
-        for (size_t k = 0; k < need; k += 3) { /* PPM stores R,G,B; a cv::Mat is B,G,R */
-            pix[k] = p[i + k + 2];
-            pix[k + 1] = p[i + k + 1];
-            pix[k + 2] = p[i + k];
-        }
+    data_off = i;
     return true;
+}
+
+/* PNM raster -> the layout a cv::Mat holds (P6 stores R,G,B; a cv::Mat is B,G,R), rows of dst_stride bytes */
+void pnm_copy(const uint8_t *src, int w, int h, int channels, uint8_t *dst, size_t dst_stride)
+{
+    const size_t row = (size_t)w * channels;
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = src + (size_t)y * row;
+        uint8_t *d = dst + (size_t)y * dst_stride;
+        if (channels == 1) memcpy(d, s, row);
+        else
+            for (size_t k = 0; k < row; k += 3) {
+                d[k] = s[k + 2];
+                d[k + 1] = s[k + 1];
+                d[k + 2] = s[k];
+            }
+    }
 }
 
 struct pose {
@@ -344,11 +360,108 @@ int main(int argc, char **argv)
     int exitCode = 0;
     vector<uint8_t> payload, pix;
 
+    /* what TrackMonocular's outputs turn into on the wire (:596-616) */
+    auto emit_tracked = [&](const ss_pose &tracked, int camera_id, double timestamp) {
+        const int trackingState = tracked.tracking_state;
+        if (trackingState == TRACKING_OK) { /* :596: a pose is shipped only while tracking is OK */
+            const pose T{tracked.position[0], tracked.position[1], tracked.position[2], tracked.quaternion[0],
+                         tracked.quaternion[1], tracked.quaternion[2], tracked.quaternion[3]};
+            send_pose_packet(fd, T, timestamp, camera_id, trackingState);
+        }
+        if (emitFeatures) {
+            ssmp::packer pk;
+            pk.pack_map(8);
+            pk.pack("type");           pk.pack("features");
+            pk.pack("timestamp");      pk.pack(timestamp);
+            pk.pack("camera_id");      pk.pack(camera_id);
+            pk.pack("tracking_state"); pk.pack(trackingState);
+            pk.pack("n_keypoints");    pk.pack((int)tracked.n_keypoints);
+            pk.pack("n_matches");      pk.pack((int)tracked.n_matches);
+            pk.pack("n_inliers");      pk.pack((int)tracked.n_inliers);
+            pk.pack("n_map_points");   pk.pack((int)tracked.n_map_points);
+            send_framed(fd, pk.buf);
+        }
+    };
+
+    /* Read-ahead (SENDSLAM_NO_PACING=1): queued frames go through an ss_pipe in batches; poses come out in frame order. */
+    const bool noPacing = env_int("SENDSLAM_NO_PACING", 0) != 0;
+    const int readAhead = noPacing ? max(1, min(64, env_int("SENDSLAM_READAHEAD", 16))) : 1;
+    ss_pipe *pipe = nullptr;
+    ss_camera pipeCam{};
+    int pipeW = 0, pipeH = 0, pipeCh = 0;
+    ss_pipe_slot openSlot{};
+    int openN = 0, batchesInFlight = 0;
+    vector<int32_t> openCams;
+    vector<double> openStamps;
+    vector<chrono::steady_clock::time_point> submitTimes; /* per batch in flight, oldest first */
+
+    /* takes the oldest completed batch (blocking), tracks its frames in order, ships poses */
+    auto finish_batch = [&]() {
+        ss_pipe_result r{};
+        if (ss_pipe_wait(pipe, &r) != SS_OK) {
+            cerr << "Frame batch lost: " << ss_pipe_last_error(pipe) << endl;
+            batchesInFlight = 0;
+            submitTimes.clear();
+            return;
+        }
+        const double extractShare = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - submitTimes.front()).count() / max(1, r.n_frames);
+        submitTimes.erase(submitTimes.begin());
+        batchesInFlight--;
+        for (int i = 0; i < r.n_frames; i++) {
+            if (r.status[i] != SS_OK) {
+                cerr << "Frame skipped: extraction failed (status " << r.status[i] << ")" << endl; /* bad frame => log + skip */
+                continue;
+            }
+            const auto t1 = chrono::steady_clock::now();
+            ss_pose tracked{};
+            const int rc = ss_track_features(ctx, r.camera_id[i], r.timestamp[i],
+                                             (const uint8_t *)r.d_descriptors + (size_t)i * r.kp_capacity * SS_DESC_BYTES,
+                                             r.keypoints + (size_t)i * r.kp_capacity, r.n_keypoints[i], &tracked);
+            if (rc != SS_OK) {
+                cerr << "Frame skipped: " << ss_last_error(ctx) << endl;
+                continue;
+            }
+            emit_tracked(tracked, r.camera_id[i], r.timestamp[i]);
+            const double ttrack = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - t1).count();
+            vTimesTrack.push_back((float)(ttrack + extractShare));
+        }
+        ss_pipe_release(pipe, r.slot);
+    };
+    auto submit_open = [&]() {
+        if (!pipe || openN == 0) return;
+        if (ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()) != SS_OK) {
+            cerr << "Frame batch skipped: " << ss_pipe_last_error(pipe) << endl;
+            ss_pipe_release(pipe, openSlot.slot);
+        } else {
+            batchesInFlight++;
+            submitTimes.push_back(chrono::steady_clock::now());
+        }
+        openN = 0;
+        openCams.clear();
+        openStamps.clear();
+    };
+    /* everything received so far is tracked and answered before the caller goes on (other message types, EOF, idle socket) */
+    auto drain_pipe = [&]() {
+        submit_open();
+        while (pipe && batchesInFlight > 0) finish_batch();
+    };
+    auto destroy_pipe = [&]() {
+        drain_pipe();
+        if (pipe) ss_pipe_destroy(pipe);
+        pipe = nullptr;
+    };
+    auto input_queued = [&]() {
+        pollfd pf{fd, POLLIN, 0};
+        return ::poll(&pf, 1, 0) > 0 && (pf.revents & POLLIN);
+    };
+
     cout << "Connection established. Awaiting calibration parameters..." << endl;
 
     while (true) {
+        if (pipe && (openN > 0 || batchesInFlight > 0) && !input_queued()) drain_pipe(); /* idle socket: answer now */
         uint8_t lengthBuffer[4];
         const int r = readExact(lengthBuffer, 4);
+        if (r <= 0) drain_pipe();
         if (r == 0) {
             cout << "Connection closed by server." << endl;
             break;
@@ -366,6 +479,7 @@ int main(int argc, char **argv)
         }
         if (messageLength > kMaxMessageSize) {
             cerr << "Message exceeds safety limit (" << messageLength << " bytes)." << endl;
+            destroy_pipe();
             if (ctx) ss_destroy(ctx);
             return 1;
         }
@@ -388,6 +502,7 @@ int main(int argc, char **argv)
             continue;
         }
 
+        if (packet.type != "frame") drain_pipe(); /* messages are answered in order */
         if (packet.type == "terminate" || packet.type == "shutdown") {
             cout << "Received termination request from server." << endl;
             break;
@@ -403,6 +518,7 @@ int main(int argc, char **argv)
                 continue;
             }
             /* a second calibration rebuilds the whole system (:491-518) */
+            destroy_pipe();
             if (ctx) {
                 ss_destroy(ctx);
                 ctx = nullptr;
@@ -426,6 +542,7 @@ int main(int argc, char **argv)
                 cerr << ss_last_error(ctx) << endl;
                 continue;
             }
+            pipeCam = cam;
             if (env_int("SENDSLAM_PRINT_SETTINGS", 0)) cout << settings_text(c, params);
             calibrationReceived = true;
             vTimesTrack.clear();
@@ -452,7 +569,8 @@ int main(int argc, char **argv)
                 continue;
             }
             int w = 0, h = 0, ch = 0;
-            if (!decode_pnm(packet.imageData, packet.imageSize, w, h, ch, pix)) {
+            size_t pnmOff = 0;
+            if (!pnm_header(packet.imageData, packet.imageSize, w, h, ch, pnmOff)) {
                 cerr << "Failed to decode frame image data." << endl;
                 continue;
             }
@@ -461,6 +579,34 @@ int main(int argc, char **argv)
                 continue;
             }
 
+            if (readAhead > 1) {
+                /* decode straight into a pinned slot; the batch goes out when it is full or the socket has run dry */
+                if (pipe && (w != pipeW || h != pipeH || ch != pipeCh)) destroy_pipe();
+                if (!pipe) {
+                    ss_pipe_config cfg{};
+                    cfg.width = w; cfg.height = h; cfg.channels = ch;
+                    cfg.batch = readAhead; cfg.depth = 3; cfg.match_mode = -1;
+                    if (ss_pipe_create(device, &params, &pipeCam, &cfg, &pipe) != SS_OK) {
+                        cerr << "Frame skipped: " << ss_pipe_last_error(nullptr) << endl;
+                        pipe = nullptr;
+                        continue;
+                    }
+                    pipeW = w; pipeH = h; pipeCh = ch;
+                }
+                if (openN == 0) {
+                    while (ss_pipe_acquire(pipe, &openSlot) == SS_ERR_BUSY) finish_batch();
+                }
+                pnm_copy(packet.imageData + pnmOff, w, h, ch, openSlot.pixels + (size_t)openN * openSlot.frame_stride, (size_t)openSlot.row_stride);
+                openCams.push_back(packet.camera_id);
+                openStamps.push_back(packet.timestamp);
+                openN++;
+                if (openN == readAhead || !input_queued()) submit_open();
+                previousTimestamp = packet.timestamp;
+                continue;
+            }
+
+            pix.resize((size_t)w * h * ch);
+            pnm_copy(packet.imageData + pnmOff, w, h, ch, pix.data(), (size_t)w * ch);
             const auto t1 = chrono::steady_clock::now();
             /* TrackMonocular :594 -> Twc + tracking state :596 */
             ss_pose tracked{};
@@ -469,32 +615,14 @@ int main(int argc, char **argv)
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl; /* bad frame => log + skip */
                 continue;
             }
-            const int trackingState = tracked.tracking_state;
-            if (trackingState == TRACKING_OK) { /* :596: a pose is shipped only while tracking is OK */
-                const pose T{tracked.position[0], tracked.position[1], tracked.position[2], tracked.quaternion[0],
-                             tracked.quaternion[1], tracked.quaternion[2], tracked.quaternion[3]};
-                send_pose_packet(fd, T, packet.timestamp, packet.camera_id, trackingState);
-            }
-            if (emitFeatures) {
-                ssmp::packer pk;
-                pk.pack_map(8);
-                pk.pack("type");           pk.pack("features");
-                pk.pack("timestamp");      pk.pack(packet.timestamp);
-                pk.pack("camera_id");      pk.pack(packet.camera_id);
-                pk.pack("tracking_state"); pk.pack(trackingState);
-                pk.pack("n_keypoints");    pk.pack((int)tracked.n_keypoints);
-                pk.pack("n_matches");      pk.pack((int)tracked.n_matches);
-                pk.pack("n_inliers");      pk.pack((int)tracked.n_inliers);
-                pk.pack("n_map_points");   pk.pack((int)tracked.n_map_points);
-                send_framed(fd, pk.buf);
-            }
+            emit_tracked(tracked, packet.camera_id, packet.timestamp);
             const auto t2 = chrono::steady_clock::now();
             const double ttrack = chrono::duration_cast<chrono::duration<double>>(t2 - t1).count();
             vTimesTrack.push_back((float)ttrack);
 
             if (previousTimestamp > 0.0) { /* never outrun the timestamps (:618-624) */
                 const double interval = packet.timestamp - previousTimestamp;
-                if (ttrack < interval && !env_int("SENDSLAM_NO_PACING", 0)) usleep((useconds_t)((interval - ttrack) * 1e6));
+                if (ttrack < interval && !noPacing) usleep((useconds_t)((interval - ttrack) * 1e6));
             }
             previousTimestamp = packet.timestamp;
             continue;
@@ -503,6 +631,7 @@ int main(int argc, char **argv)
         cerr << "Received MessagePack with unsupported type: '" << packet.type << "'." << endl;
     }
 
+    destroy_pipe();
     ::shutdown(fd, SHUT_RDWR);
     ::close(fd);
 

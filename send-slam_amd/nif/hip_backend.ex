@@ -10,6 +10,11 @@ defmodule SendSlam.HipNif do
   def extract(_ref, _camera_id, _pixels, _w, _h, _channels, _timestamp), do: :erlang.nif_error(:nif_not_loaded)
   def match(_ref, _query, _train, _th, _num, _den), do: :erlang.nif_error(:nif_not_loaded)
   def track(_ref, _camera_id, _pixels, _w, _h, _channels, _timestamp), do: :erlang.nif_error(:nif_not_loaded)
+  def track_reset(_ref), do: :erlang.nif_error(:nif_not_loaded)
+  # pipelined host-memory path (ss_pipe_*): lists of Mat binaries in, lists of per-frame results out
+  def pipe_open(_device, _n_features, _w, _h, _channels, _batch, _depth, _match_mode, _rgb), do: :erlang.nif_error(:nif_not_loaded)
+  def pipe_submit(_pipe, _frames, _camera_id, _first_timestamp, _dt), do: :erlang.nif_error(:nif_not_loaded)
+  def pipe_wait(_pipe), do: :erlang.nif_error(:nif_not_loaded)
 end
 
 defmodule SendSlam.HipBackend do
@@ -129,6 +134,8 @@ defmodule SendSlam.HipBackend do
   end
 
   def handle_info(:auto_start, s), do: {:noreply, s}
+  # A new calibration: the next frame calls set_calibration again, and ss_set_calibration resets the tracker (map,
+  # reference frame, motion model) like the shim's rebuild of the whole System (orbslam3_mono_networked.cc:491-518).
   def handle_info({:broadcast_message, {:calibration, _calib}}, s), do: {:noreply, %{s | calibrated: false}}
   def handle_info(_other, s), do: {:noreply, s}
 

@@ -150,11 +150,116 @@ static ERL_NIF_TERM nif_track(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[
     return enif_make_tuple5(env, enif_make_atom(env, "ok"), enif_make_int(env, po.tracking_state), pos, quat, cnt);
 }
 
+/* track_reset(ref) -> :ok   (System::Reset; ss_set_calibration resets by itself, like the shim's rebuild :491-518) */
+static ERL_NIF_TERM nif_track_reset(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    ctx_res *r;
+    (void)argc;
+    if (!enif_get_resource(env, argv[0], CTX_TYPE, (void **)&r)) return enif_make_badarg(env);
+    ss_track_reset(r->ctx);
+    return enif_make_atom(env, "ok");
+}
+
+/* ---- pipelined host-memory path (ss_pipe_*): a GenServer that receives frames faster than one ss_track call per
+ * frame returns (several cameras, a replay producer) hands lists of Mat binaries to pipe_submit and collects the
+ * batches with pipe_wait; copies and kernels of different batches overlap inside the library. ---- */
+static ErlNifResourceType *PIPE_TYPE;
+typedef struct { ss_pipe *pipe; int w, h, ch; } pipe_res;
+
+static void pipe_dtor(ErlNifEnv *env, void *obj)
+{
+    (void)env;
+    pipe_res *r = (pipe_res *)obj;
+    if (r->pipe) ss_pipe_destroy(r->pipe);
+    r->pipe = NULL;
+}
+
+/* pipe_open(device, n_features, width, height, channels, batch, depth, match_mode, rgb) -> {:ok, pipe} | error */
+static ERL_NIF_TERM nif_pipe_open(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    int v[9];
+    (void)argc;
+    for (int i = 0; i < 9; i++)
+        if (!enif_get_int(env, argv[i], &v[i])) return enif_make_badarg(env);
+    ss_orb_params p;
+    ss_orb_params_default(&p);
+    if (v[1] > 0) p.n_features = v[1];
+    ss_pipe_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.width = v[2]; cfg.height = v[3]; cfg.channels = v[4]; cfg.batch = v[5]; cfg.depth = v[6]; cfg.match_mode = v[7];
+    ss_camera cam;
+    memset(&cam, 0, sizeof(cam));
+    strcpy(cam.type, "PinHole");
+    cam.width = v[2]; cam.height = v[3]; cam.rgb = v[8];
+    ss_pipe *pipe = NULL;
+    int rc = ss_pipe_create(v[0], &p, &cam, &cfg, &pipe);
+    if (rc != SS_OK) return mk_error(env, rc, ss_pipe_last_error(NULL));
+    pipe_res *r = enif_alloc_resource(PIPE_TYPE, sizeof(pipe_res));
+    r->pipe = pipe; r->w = v[2]; r->h = v[3]; r->ch = v[4];
+    ERL_NIF_TERM t = enif_make_resource(env, r);
+    enif_release_resource(r);
+    return enif_make_tuple2(env, enif_make_atom(env, "ok"), t);
+}
+
+/* pipe_submit(pipe, frames :: [binary], camera_id, first_timestamp, dt) -> :ok | {:error, {-10, _}} when the ring is full */
+static ERL_NIF_TERM nif_pipe_submit(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    pipe_res *r;
+    int cam_id;
+    double ts0, dt;
+    unsigned n = 0;
+    (void)argc;
+    if (!enif_get_resource(env, argv[0], PIPE_TYPE, (void **)&r) || !enif_get_list_length(env, argv[1], &n) ||
+        !enif_get_int(env, argv[2], &cam_id) || !enif_get_double(env, argv[3], &ts0) || !enif_get_double(env, argv[4], &dt))
+        return enif_make_badarg(env);
+    if (n == 0 || n > 256) return mk_error(env, SS_ERR_INVALID_ARG, "1..256 frames per batch");
+    const uint8_t *ptrs[256];
+    int32_t cams[256];
+    double stamps[256];
+    ERL_NIF_TERM head, tail = argv[1];
+    const size_t need = (size_t)r->w * r->h * r->ch;
+    for (unsigned i = 0; i < n; i++) {
+        ErlNifBinary b;
+        if (!enif_get_list_cell(env, tail, &head, &tail)) return enif_make_badarg(env);
+        ptrs[i] = (enif_inspect_binary(env, head, &b) && b.size >= need) ? b.data : NULL; /* NULL = this frame is skipped */
+        cams[i] = cam_id;
+        stamps[i] = ts0 + dt * i;
+    }
+    int rc = ss_pipe_submit_frames(r->pipe, ptrs, (int)n, (int64_t)r->w * r->ch, cams, stamps);
+    return rc == SS_OK ? enif_make_atom(env, "ok") : mk_error(env, rc, ss_pipe_last_error(r->pipe));
+}
+
+/* pipe_wait(pipe) -> {:ok, [{status, camera_id, timestamp, n, keypoints :: binary, descriptors :: binary, match_idx :: binary}]} */
+static ERL_NIF_TERM nif_pipe_wait(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    pipe_res *r;
+    (void)argc;
+    if (!enif_get_resource(env, argv[0], PIPE_TYPE, (void **)&r)) return enif_make_badarg(env);
+    ss_pipe_result res;
+    int rc = ss_pipe_wait(r->pipe, &res);
+    if (rc != SS_OK) return mk_error(env, rc, ss_pipe_last_error(r->pipe));
+    ERL_NIF_TERM items[256];
+    for (int i = 0; i < res.n_frames; i++) {
+        const size_t n = (size_t)res.n_keypoints[i], row = (size_t)i * res.kp_capacity;
+        ERL_NIF_TERM kb, db, mb;
+        memcpy(enif_make_new_binary(env, n * sizeof(ss_keypoint), &kb), res.keypoints + row, n * sizeof(ss_keypoint));
+        memcpy(enif_make_new_binary(env, n * SS_DESC_BYTES, &db), res.descriptors + row * SS_DESC_BYTES, n * SS_DESC_BYTES);
+        unsigned char *mp = enif_make_new_binary(env, res.match_idx ? n * 4 : 0, &mb);
+        if (res.match_idx) memcpy(mp, res.match_idx + row, n * 4);
+        items[i] = enif_make_tuple(env, 7, enif_make_int(env, res.status[i]), enif_make_int(env, res.camera_id[i]),
+                                   enif_make_double(env, res.timestamp[i]), enif_make_int(env, (int)n), kb, db, mb);
+    }
+    ERL_NIF_TERM list = enif_make_list_from_array(env, items, (unsigned)res.n_frames);
+    ss_pipe_release(r->pipe, res.slot); /* everything was copied into BEAM binaries */
+    return enif_make_tuple2(env, enif_make_atom(env, "ok"), list);
+}
+
 static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info)
 {
     (void)priv; (void)info;
     CTX_TYPE = enif_open_resource_type(env, NULL, "sendslam_ctx", ctx_dtor, ERL_NIF_RT_CREATE, NULL);
-    return CTX_TYPE ? 0 : 1;
+    PIPE_TYPE = enif_open_resource_type(env, NULL, "sendslam_pipe", pipe_dtor, ERL_NIF_RT_CREATE, NULL);
+    return CTX_TYPE && PIPE_TYPE ? 0 : 1;
 }
 
 static ErlNifFunc funcs[] = {
@@ -163,6 +268,10 @@ static ErlNifFunc funcs[] = {
     {"extract", 7, nif_extract, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"match", 6, nif_match, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"track", 7, nif_track, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"track_reset", 1, nif_track_reset, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"pipe_open", 9, nif_pipe_open, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"pipe_submit", 5, nif_pipe_submit, ERL_NIF_DIRTY_JOB_CPU_BOUND},
+    {"pipe_wait", 1, nif_pipe_wait, ERL_NIF_DIRTY_JOB_IO_BOUND}, /* blocks on the GPU, burns no CPU */
 };
 
 ERL_NIF_INIT(Elixir.SendSlam.HipNif, funcs, on_load, NULL, NULL, NULL)

@@ -35,6 +35,9 @@ ERL_NIF_TERM enif_make_double(ErlNifEnv *, double);
 ERL_NIF_TERM enif_make_string(ErlNifEnv *, const char *, ErlNifCharEncoding);
 ERL_NIF_TERM enif_make_badarg(ErlNifEnv *);
 ERL_NIF_TERM enif_make_tuple(ErlNifEnv *, unsigned, ...);
+int enif_get_list_length(ErlNifEnv *, ERL_NIF_TERM, unsigned *);
+int enif_get_list_cell(ErlNifEnv *, ERL_NIF_TERM, ERL_NIF_TERM *, ERL_NIF_TERM *);
+ERL_NIF_TERM enif_make_list_from_array(ErlNifEnv *, const ERL_NIF_TERM[], unsigned);
 #define enif_make_tuple2(env, a, b) enif_make_tuple(env, 2, a, b)
 #define enif_make_tuple3(env, a, b, c) enif_make_tuple(env, 3, a, b, c)
 #define enif_make_tuple4(env, a, b, c, d) enif_make_tuple(env, 4, a, b, c, d)

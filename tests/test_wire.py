@@ -185,11 +185,15 @@ def test_frontdoor_without_gpu_fails_loudly_at_calibration(frontdoor):
 
 
 @pytest.mark.gpu
-def test_frontdoor_end_to_end_frames(frontdoor, oracle):
+@pytest.mark.parametrize("extra_env", [{"SENDSLAM_READAHEAD": "1"}, {"SENDSLAM_READAHEAD": "4"}], ids=["frame_by_frame", "read_ahead"])
+def test_frontdoor_end_to_end_frames(frontdoor, oracle, extra_env):
     """Config 1 of BASELINE.json: fake host <-> front door, calibration then frames of a parallax
     sequence.  Every frame goes through ss_track on the GPU; a pose packet is sent exactly for the
     frames whose tracking state is OK (shim :596) and equals the all-CPU pipeline's pose; the optional
-    'features' message carries the counts of that pipeline."""
+    'features' message carries the counts of that pipeline.  read_ahead: the same stream (run_backend sets
+    SENDSLAM_NO_PACING=1) with SENDSLAM_READAHEAD=4 instead of 1 -- queued frames are decoded into pinned slots of an ss_pipe, extracted in batches of up
+    to 4 and tracked in order by ss_track_features (the colour frame changes the geometry mid-stream: the pipe is
+    drained and rebuilt): same messages in the same order."""
     import track_ref
     from oracle import vo_oracle as vo
     w, h, seed = 640, 480, 77
@@ -197,7 +201,7 @@ def test_frontdoor_end_to_end_frames(frontdoor, oracle):
     frames = [synth.parallax_frame(seed, w, h, t, sc=sc) for t in range(6)]
     col = synth.color_frame(41, w, h)
     host = FakeHost()
-    b = run_backend(host, {"SENDSLAM_EMIT_FEATURES": "1"})
+    b = run_backend(host, dict({"SENDSLAM_EMIT_FEATURES": "1"}, **extra_env))
     gray = lambda c: oracle.gray(np.ascontiguousarray(c), 1)  # PPM is R,G,B on the wire, a BGR Mat after decode, rgb: 1
     want = track_ref.run(oracle, frames + [col], vo.Camera(500, 500, 320, 240), 1250, gray=gray)
     n_expected = len(want) + sum(o["state"] == 2 for o in want)
