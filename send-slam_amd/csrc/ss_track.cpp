@@ -1090,6 +1090,24 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
     }
     pose_hist.insert(pose_hist.end(), cur.R, cur.R + 9);
     pose_hist.insert(pose_hist.end(), cur.t, cur.t + 3);
+    /* one long-lived process per camera: keep only the poses an anchored track still refers to (and the newest, which the
+     * next frame reads as prev's), so the history does not grow with the length of the run */
+    if (pose_hist.size() / 12 > (size_t)std::max(pose_hist_cap, 1)) {
+        const size_t n_pose = pose_hist.size() / 12;
+        std::vector<int32_t> remap(n_pose, -1);
+        for (int i = 0; i < n; i++)
+            if (cur.anchor[i] >= 0) remap[(size_t)cur.anchor[i]] = 0;
+        remap[n_pose - 1] = 0;
+        size_t kept = 0;
+        for (size_t k = 0; k < n_pose; k++) {
+            if (remap[k] < 0) continue;
+            if (kept != k) std::copy(pose_hist.begin() + 12 * k, pose_hist.begin() + 12 * (k + 1), pose_hist.begin() + 12 * kept);
+            remap[k] = (int32_t)kept++;
+        }
+        pose_hist.resize(12 * kept);
+        for (int i = 0; i < n; i++)
+            if (cur.anchor[i] >= 0) cur.anchor[i] = remap[(size_t)cur.anchor[i]];
+    }
     for (int i = 0; i < n; i++) out.n_map_points += cur.has3d[i];
     { /* mVelocity = Tcw * Twc_last */
         double Rpt[9];
@@ -1098,8 +1116,8 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
         for (int r = 0; r < 3; r++) vel_t[r] = cur.t[r] - (vel_R[3 * r] * prev.t[0] + vel_R[3 * r + 1] * prev.t[1] + vel_R[3 * r + 2] * prev.t[2]);
         have_vel = true;
     }
-    prev = cur;
     out.state = 2;
     sst_pose_to_twc(cur.R, cur.t, out.pos, out.quat);
+    prev = std::move(cur);
     return SST_KEEP_AS_PREV;
 }

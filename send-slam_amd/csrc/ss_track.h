@@ -99,7 +99,8 @@ struct sst_tracker {
     bool have_ref = false, have_vel = false;
     double vel_R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, vel_t[3] = {0, 0, 0}; /* Tcw(k) * Twc(k-1) */
     sst_frame ref, prev;
-    std::vector<double> pose_hist; /* 12 doubles (R, t) per tracked frame since initialisation */
+    std::vector<double> pose_hist; /* 12 doubles (R, t) per tracked frame an anchored track still refers to */
+    int pose_hist_cap = 256;       /* poses kept before the unreferenced ones are dropped (results do not depend on it) */
 
     void reset();
     /* which stored descriptor set the next frame's descriptors are to be matched against */

@@ -56,6 +56,8 @@ void *shim_tracker_new(const double *cam, double scale_factor)
     return tr;
 }
 void shim_tracker_free(void *p) { delete (sst_tracker *)p; }
+void shim_tracker_set_hist_cap(void *p, int cap) { ((sst_tracker *)p)->pose_hist_cap = cap; }
+int shim_tracker_hist_len(void *p) { return (int)(((sst_tracker *)p)->pose_hist.size() / 12); }
 int shim_tracker_want(void *p) { return ((sst_tracker *)p)->want_match(); }
 int shim_tracker_n_train(void *p) { return ((sst_tracker *)p)->n_train(); }
 int shim_tracker_step(void *p, int n, const float *xy, const int32_t *oct, const int32_t *idx, const uint16_t *d1, double *pose7, int32_t *counts4)

@@ -32,6 +32,8 @@ def shim(tmp_path_factory):
     lib.shim_tracker_free.argtypes = [C.c_void_p]
     lib.shim_tracker_want.argtypes = [C.c_void_p]
     lib.shim_tracker_n_train.argtypes = [C.c_void_p]
+    lib.shim_tracker_set_hist_cap.argtypes = [C.c_void_p, C.c_int]
+    lib.shim_tracker_hist_len.argtypes = [C.c_void_p]
     lib.shim_tracker_step.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
     lib.shim_triangulate.argtypes = [C.c_void_p] * 7 + [C.c_double, C.c_double, C.c_void_p]
     return lib
@@ -412,9 +414,18 @@ def test_tracker_on_parallax_sequence_product_vs_oracle_vs_truth(shim, oracle):
     def match(q, t):
         return oracle.match(q, t, 50, 9, 10, False)
 
-    prod, ref = ShimTracker(shim, cam, 1.2), vo.Tracker(cam, 1.2)
-    outs = run_sequence(frames, extract, match, [prod, ref])
+    # a third tracker drops unreferenced poses of its history after every frame (cap 2 instead of 256): a
+    # long-lived front door must not grow with the run, and the poses must not depend on the compaction
+    prod, ref, small = ShimTracker(shim, cam, 1.2), vo.Tracker(cam, 1.2), ShimTracker(shim, cam, 1.2)
+    shim.shim_tracker_set_hist_cap(small.h, 2)
+    outs3 = run_sequence(frames, extract, match, [prod, ref, small])
+    assert shim.shim_tracker_hist_len(small.h) < shim.shim_tracker_hist_len(prod.h) == sum(o[0]["state"] == 2 for o in outs3)
+    for a, _, c in outs3:
+        assert (a["state"], a["n_matches"], a["n_inliers"], a["n_map_points"]) == (c["state"], c["n_matches"], c["n_inliers"], c["n_map_points"])
+        assert np.array_equal(a["position"], c["position"]) and np.array_equal(a["quaternion"], c["quaternion"])
+    outs = [o[:2] for o in outs3]
     prod.close()
+    small.close()
     states = [o[0]["state"] for o in outs]
     assert states[0] == 1 and states[-1] == 2 and 4 not in states
     first_ok = states.index(2)
