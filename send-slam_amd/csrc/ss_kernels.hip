@@ -279,10 +279,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     /* `score` may be NULL: no later kernel reads the response map (it exists for stage-by-stage tests) */
     /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
      * so the vertical pass is four v_dot2_u32_u16 per output */
-    __shared__ uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
+    __shared__ __attribute__((aligned(16))) uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
     __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
     /* scores of the tile and of its 1-px ring: row ly + 1, byte lx + 4 (tile pixels dword-aligned) */
-    __shared__ uint32_t out_tile[SS_TILE_H2 + 2][FT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t out_tile[SS_TILE_H2 + 2][FT_WORDS];
     __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2 + FT_HALO_PIXELS + 4];
     __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H2];
     __shared__ uint16_t xinf[SS_TILE_W], yinf[SS_TILE_H2];
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < (SS_TILE_H2 + 2) * FT_WORDS; i += FT_THREADS) (&out_tile[0][0])[i] = 0;
+    static_assert(((SS_TILE_H2 + 2) * FT_WORDS) % 4 == 0 && ((SS_TILE_H2 + 2) * FT_WORDS) / 4 <= FT_THREADS, "out_tile is cleared by one 16-byte store per thread");
+    if (threadIdx.x < (SS_TILE_H2 + 2) * FT_WORDS / 4) ((uint4 *)&out_tile[0][0])[threadIdx.x] = make_uint4(0, 0, 0, 0);
     /* window info of the tile's columns / rows: requested now, stored to LDS after the staging loads have been issued,
      * so that the block waits for the two kinds of loads once, not one after the other */
     uint16_t cinf_v = 0;
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * pixel whose ring leaves the image, so it does not care).  Rows are always reflected (4
      * ops); columns only in the tiles that touch the left / right image edge (block-uniform). */
     const bool inner_x = x0 >= 4 && x0 + 68 <= w;
-    if (inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h) {
+    const bool interior = inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h;
+    if (interior) {
         /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
         const uint8_t *tile0 = img + (size_t)(y0 - 4) * ipitch + (x0 - 4);
         const uint32_t off = __umul24((uint32_t)ty, (uint32_t)ipitch) + 4u * (uint32_t)tx;
@@ -333,23 +335,29 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             }
         }
     } else {
+        /* a tile at the image rim: rows by reflected row index; columns as the same aligned dwords wherever their
+         * first byte is inside the row (a level's rows are padded to the pitch, the caller's rows to 16 bytes), and a
+         * fix-up pass below for the few bytes BORDER_REFLECT_101 defines outside [0, w) */
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
             const int r = ty + (FT_THREADS / 16) * rr;
             if (r < FT_ROWS) {
                 const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * ipitch;
-                if (inner_x) {
-                    lds[r][tx] = *(const uint32_t *)(row + x0 - 4 + 4 * tx);
-                    if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(row + x0 + 60 + 4 * tx);
-                } else {
-                    for (int c = tx; c < FT_WORDS; c += 16) {
-                        const int gx = x0 - 4 + 4 * c;
-                        uint32_t v = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(gx + b, w)] << (8 * b);
-                        lds[r][c] = v;
-                    }
-                }
+                const int gx = x0 - 4 + 4 * tx;
+                lds[r][tx] = (gx >= 0 && gx < w) ? *(const uint32_t *)(row + gx) : 0u;
+                if (tx < 2) lds[r][16 + tx] = (gx + 64 < w) ? *(const uint32_t *)(row + gx + 64) : 0u;
+            }
+        }
+        if (!inner_x) {
+            /* the blur reads up to 3 px outside the row (x = -3 .. -1 mirror 3 .. 1, x = w .. w+2 mirror w-2 .. w-4); FAST
+             * never evaluates a pixel whose ring leaves the image.  Sources and destinations are inside the staged window. */
+            __syncthreads();
+            uint8_t *t8 = (uint8_t *)&lds[0][0];
+            for (int i = threadIdx.x; i < FT_ROWS * 6; i += FT_THREADS) {
+                const int r = i / 6, k = i - 6 * r;
+                const int x = k < 3 ? -1 - k : w + (k - 3), sx = k < 3 ? 1 + k : w - 2 - (k - 3);
+                const int bx = x - (x0 - 4), bs = sx - (x0 - 4);
+                if (bx >= 0 && bx < 4 * FT_WORDS && bs >= 0 && bs < 4 * FT_WORDS) t8[r * (4 * FT_WORDS) + bx] = t8[r * (4 * FT_WORDS) + bs];
             }
         }
     }
@@ -364,7 +372,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * the rest get 0 without the 100-op arc search. */
     const int min_th = g->min_th;
     const uint8_t *tile8 = (const uint8_t *)&lds[0][0];
-    uint32_t cand_bits = 0; /* bit 4*rr + i: pixel i of row 2ty+rr passed */
+    /* pixel i of row 2ty + rr passed <=> bit 8 i + 3 + 4 rr of cand_bits (the sign bits of min_th - c, gathered by one
+     * v_perm_b32 per row) */
+    uint32_t cand_bits = 0;
+    const i16x2 th2 = as_i16x2((uint32_t)min_th * 0x00010001u);
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
@@ -372,6 +383,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
          * differences and the min/max tree are v_pk_*_i16 */
         const uint32_t u1 = lds[ly + 1][tx + 1], n1 = lds[ly + 7][tx + 1];
         const uint32_t m0 = lds[ly + 4][tx], m1 = lds[ly + 4][tx + 1], m2 = lds[ly + 4][tx + 2];
+        uint32_t neg[2];
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) { /* pixels 2pr, 2pr+1 of the thread's four */
             constexpr uint32_t Z = 0x0C000C00u; /* selector bytes 1 and 3 = constant 0 */
@@ -387,16 +399,32 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             const i16x2 lo_pairs = __builtin_elementwise_max(__builtin_elementwise_min(pd, pu), __builtin_elementwise_min(pr3, pl3));
             const i16x2 hi_pairs = __builtin_elementwise_min(__builtin_elementwise_max(pd, pu), __builtin_elementwise_max(pr3, pl3));
             const i16x2 c = __builtin_elementwise_max(v - lo_pairs, hi_pairs - v);
-            cand_bits |= ((int)c[0] > min_th ? 1u : 0u) << (4 * rr + 2 * pr);
-            cand_bits |= ((int)c[1] > min_th ? 1u : 0u) << (4 * rr + 2 * pr + 1);
+            neg[pr] = __builtin_bit_cast(uint32_t, th2 - c); /* |c| <= 255: no wrap; negative <=> c > min_th */
         }
+        /* bytes 1 and 3 of neg[0], then of neg[1]: their top bits are the four verdicts, in pixel order */
+        const uint32_t signs = __builtin_amdgcn_perm(neg[1], neg[0], 0x07050301u) & 0x80808080u;
+        cand_bits |= rr ? signs : signs >> 4;
     }
-    while (cand_bits) { /* rare: a few % of the pixels */
-        const int bit = __builtin_ctz(cand_bits);
-        cand_bits &= cand_bits - 1;
-        const int ly = 2 * ty + (bit >> 2), lx = 4 * tx + (bit & 3);
-        const int x = x0 + lx, y = y0 + ly;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
+    if (!interior) {
+        /* rim tiles: FAST evaluates 3 <= x < w - 3, 3 <= y < h - 3 only */
+        uint32_t ok = 0;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = x0 + 4 * tx + i, y = y0 + 2 * ty + rr;
+                ok |= (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) ? 1u << (8 * i + 3 + 4 * rr) : 0u;
+            }
+        cand_bits &= ok;
+    }
+    if (cand_bits) { /* rare: a few % of the pixels.  One LDS atomic per lane reserves its slots (the queue is unordered) */
+        uint32_t slot = atomicAdd(&n_list, (int)__popc(cand_bits));
+        const uint32_t code0 = (uint32_t)(((2 * ty + 1) << 8) | (4 * tx + 1));
+        do {
+            const uint32_t bit = (uint32_t)__builtin_ctz(cand_bits);
+            cand_bits &= cand_bits - 1;
+            list[slot++] = (uint16_t)(code0 + (bit >> 3) + ((bit & 4u) << 6)); /* (ly + 1) << 8 | (lx + 1) */
+        } while (cand_bits);
     }
     /* the same test for the 1-px ring around the tile (scores the NMS of the edge pixels needs) */
     if (threadIdx.x < FT_HALO_PIXELS) {
@@ -420,21 +448,24 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     {
         constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
         constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
-        uint16_t *h16 = (uint16_t *)&hpair[0][0];
+        /* one item = four pixels of the two rows of a pair: 16 dot products, ONE 16-byte LDS store */
 #pragma unroll
-        for (int it = 0; it < (FT_BLUR_ROWS * 16 + FT_THREADS - 1) / FT_THREADS; it++) {
+        for (int it = 0; it < ((FT_BLUR_ROWS / 2) * 16 + FT_THREADS - 1) / FT_THREADS; it++) {
             const int idx = (int)threadIdx.x + FT_THREADS * it;
-            if (idx >= FT_BLUR_ROWS * 16) break;
-            const int r = idx >> 4, q = idx & 15; /* blur row r = staged row r + 1 */
-            const uint32_t w0 = lds[r + 1][q], w1 = lds[r + 1][q + 1], w2 = lds[r + 1][q + 2];
-            uint32_t hv[4];
-            hv[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
-            hv[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
-            hv[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
-            hv[3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
-            uint16_t *dst = h16 + ((size_t)(r >> 1) * SS_TILE_W + 4 * q) * 2 + (r & 1);
+            if (idx >= (FT_BLUR_ROWS / 2) * 16) break;
+            const int pair = idx >> 4, q = idx & 15; /* blur rows 2 pair, 2 pair + 1 = staged rows + 1 */
+            uint32_t hv[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) dst[2 * i] = (uint16_t)hv[i];
+            for (int k = 0; k < 2; k++) {
+                const uint32_t w0 = lds[2 * pair + k + 1][q], w1 = lds[2 * pair + k + 1][q + 1], w2 = lds[2 * pair + k + 1][q + 2];
+                hv[k][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
+                hv[k][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
+                hv[k][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
+                hv[k][3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
+            }
+            /* sums stay below 2^16 (255 * 256) */
+            *(uint4 *)&hpair[pair][4 * q] = make_uint4(hv[0][0] | (hv[1][0] << 16), hv[0][1] | (hv[1][1] << 16),
+                                                       hv[0][2] | (hv[1][2] << 16), hv[0][3] | (hv[1][3] << 16));
         }
     }
     __syncthreads();
