@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, "send-slam_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "send-slam_amd"))
 from send_slam_amd import binding, synth
 if os.environ.get("SENDSLAM_LIB"): binding.LIB_PATH = os.environ["SENDSLAM_LIB"]
 B, n = 64, 2000

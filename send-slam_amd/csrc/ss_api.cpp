@@ -49,6 +49,7 @@ struct ss_ctx {
     std::string err;
     bool calibrated = false;
     bool force_ingest = false; /* SENDSLAM_FORCE_INGEST=1: always copy level 0 into the pyramid block (tests) */
+    bool no_desc_x = false;    /* SENDSLAM_MATCH_PACKED=1: batch matches run k_match_mfma on the packed descriptors (A/B tests) */
     ss_camera cam{};
     int cam_id = 0;
 
@@ -74,6 +75,7 @@ struct ss_ctx {
     int32_t *n_kp = nullptr, *level_counts = nullptr, *frame_error = nullptr;
     ss_keypoint *kps = nullptr;
     uint8_t *desc = nullptr;
+    uint8_t *desc_x = nullptr; /* the descriptors as 256 bytes of +1 / -1 per row: operand of the batch matcher */
 
     uint8_t *d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -204,6 +206,7 @@ void free_geometry_buffers(ss_ctx *c)
     dev_free(c->frame_error);
     dev_free(c->kps);
     dev_free(c->desc);
+    dev_free(c->desc_x);
     c->have_geom = false;
 }
 
@@ -255,6 +258,11 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMemset(c->n_kp, 0, B * sizeof(int32_t)));
     HIP_TRY(c, hipMemset(c->kps, 0, B * g.kcap * sizeof(ss_keypoint)));
     HIP_TRY(c, hipMemset(c->desc, 0, B * g.kcap * SS_DESC_BYTES));
+    if (!c->no_desc_x && g.kcap >= SSK_MATCH_MFMA_MIN_QUERIES) {
+        /* zeroed once: a row that was never written contributes 0 to every dot product (and is masked out anyway) */
+        HIP_TRY(c, hipMalloc((void **)&c->desc_x, B * g.kcap * 256));
+        HIP_TRY(c, hipMemset(c->desc_x, 0, B * g.kcap * 256));
+    }
     c->have_geom = true;
     c->last_n_frames = 0;
     return SS_OK;
@@ -321,7 +329,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     }
     {
         stage_timer t(c, "orient_describe", (int64_t)n * g.n_features * (709 + 512 + 32 + 24));
-        ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n, l0, c->params.steer_fma != 0);
+        ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n, l0, c->params.steer_fma != 0, c->desc_x);
     }
     HIP_TRY(c, hipGetLastError());
     c->last_n_frames = n;
@@ -402,6 +410,7 @@ int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
     c->device = device_ordinal;
     c->params = p;
     if (const char *e = getenv("SENDSLAM_FORCE_INGEST")) c->force_ingest = atoi(e) != 0;
+    if (const char *e = getenv("SENDSLAM_MATCH_PACKED")) c->no_desc_x = atoi(e) != 0;
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
@@ -624,7 +633,16 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
     if ((mode != 0 && mode != 1) || !d_idx || !d_d1 || !d_d2 || ratio_den <= 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
     const int n = c->last_n_frames, kcap = c->hg.kcap;
     int chunk_len = 4;
-    const int n_chunks = ssk_match_chunks(kcap, kcap, n, &chunk_len);
+    int n_chunks = ssk_match_chunks(kcap, kcap, n, &chunk_len);
+    if (c->desc_x) {
+        if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) { /* experiment knob */
+            const int want = atoi(e);
+            if (want >= 1) {
+                chunk_len = ((kcap + want - 1) / want + 31) & ~31;
+                n_chunks = (kcap + chunk_len - 1) / chunk_len;
+            }
+        }
+    }
     if (n_chunks > 1) {
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n * n_chunks * kcap * SSK_MATCH_PARTIAL_BYTES);
         if (rc != SS_OK) return rc;
@@ -632,9 +650,14 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
     {
         const int64_t nf = c->hg.n_features;
         stage_timer t(c, "match", (int64_t)n * (nf * 32 * 2 + nf * 8));
-        ssk_match(c->stream, c->desc, c->desc, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 8, (int64_t)kcap * 8,
-                  mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
-                  c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
+        if (c->desc_x)
+            ssk_match_x(c->stream, c->desc_x, c->desc_x, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 256, (int64_t)kcap * 256,
+                        mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
+                        c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
+        else
+            ssk_match(c->stream, c->desc, c->desc, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 8, (int64_t)kcap * 8,
+                      mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
+                      c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
     }
     HIP_TRY(c, hipGetLastError());
     return SS_OK;

@@ -38,7 +38,7 @@ void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_l
                int32_t *n_kp, int32_t *level_counts, int32_t *frame_error, int n_frames);
 void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
                          const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
-                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma);
+                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma, uint8_t *desc_x);
 
 /* train split so that a launch has >> 256 workgroups and local indices fit 16 bits */
 int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_len);
@@ -53,6 +53,12 @@ void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, con
 /* cross-shard fold: parts [n_parts][nq] in ascending row order -> final outputs (k_match_merge's rule) */
 void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int th, int rnum, int rden, int32_t *idx,
                     uint16_t *d1, uint16_t *d2);
+/* the matrix-core matcher on descriptors already expanded to one +1 / -1 byte per bit (desc_x, 256 B per row, written by
+ * ssk_orient_describe): batches of frames; frame strides in BYTES; >= 128 rows per frame, multiples of 32 allocated */
+void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
+                 int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
+                 int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
+                 uint16_t *d1, uint16_t *d2, int n_frames);
 /* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8

@@ -1424,7 +1424,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
                                                          const uint32_t *__restrict__ kp_ref,
                                                          const int32_t *__restrict__ n_kp,
                                                          ss_keypoint *__restrict__ kps, uint8_t *__restrict__ desc,
-                                                         const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
+                                                         const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs,
+                                                         uint8_t *__restrict__ desc_x)
 {
     /* all blocks of a frame on one XCD: keypoints whose patches share 64-B lines then share an L2 */
     const int logical = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
@@ -1526,6 +1527,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     uint64_t words[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) words[k] = __ballot(t0[k] < t1[k]);
+    if (desc_x) {
+        /* the same 256 bits as bytes: bit b of the descriptor -> byte b = +64 (set) / -64 (clear).  k_match_mfma_x reads
+         * these rows as i8 MFMA operands (the dot product of a row with a sign-flipped row is 8192 * hamming - 2^20)
+         * without expanding anything in its loop.  Lane L writes bytes 4 L .. 4 L + 3 = bits 4 L .. 4 L + 3: one coalesced
+         * 256-byte store per wave.  Nibble -> four 0 / 1 bytes by one multiplication, then 0 -> 0xC0, 1 -> 0x40. */
+        const uint64_t wsel = lane < 16 ? words[0] : lane < 32 ? words[1] : lane < 48 ? words[2] : words[3];
+        const uint32_t nib = (uint32_t)(wsel >> (4 * (lane & 15))) & 15u;
+        const uint32_t b01 = (nib * 0x00204081u) & 0x01010101u;
+        *(uint32_t *)(desc_x + ((size_t)frame * g->kcap + slot) * 256 + 4 * lane) = 0xC0C0C0C0u ^ (b01 << 7);
+    }
     if (lane == 0) {
         uint64_t *d = (uint64_t *)(desc + ((size_t)frame * g->kcap + slot) * SS_DESC_BYTES);
         d[0] = words[0];
@@ -1911,6 +1922,207 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
     }
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* K7 on the matrix cores, operands already expanded (k_orient_describe's desc_x: one byte per descriptor bit, +64 / -64). */
+/* Same contraction, same rule, same grid contract and outputs as k_match_mfma, but the loop neither expands nor forms     */
+/* keys:                                                                                                                    */
+/* * a 32-row train tile is 8 KB of consecutive bytes that the block copies global -> LDS by LDS-DMA                        */
+/*   (global_load_lds_dwordx4: no VGPR, no VALU, no lookup table) one phase ahead of the MFMAs that read it; the query       */
+/*   fragments are eight 16-byte global loads per lane, sign-flipped once (x ^ 0x80: +64 <-> -64).  LDS image: rows at a     */
+/*   272-byte pitch (ds_read_b128 of 32 rows x 16 bytes is conflict-free there); a DMA instruction writes 64 consecutive     */
+/*   16-byte units, so each lane's SOURCE address places the padding (unit u -> row u / 17, piece u % 17; piece 16 = pad).   */
+/* * products are +-4096, so the 256-term dot product is 8192 * hamming - 2^20, and the accumulator INPUT of a tile is      */
+/*   2^20 + the row's index in the chunk: the MFMA result IS the key 8192 * hamming + row (smallest key = best distance at   */
+/*   the lowest row, second smallest carries the second-best distance).  The row-index vector advances by 32 per tile with   */
+/*   one extra MFMA (A0 = 4, B0 = 8 in k-slot 0: +32 everywhere) instead of 16 VALU additions per lane: the matrix pipe has   */
+/*   the room, the VALU does not.  Selection: v_med3_u32 + v_min_u32 per pair, nothing else.                                  */
+/* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their accumulator input, in the      */
+/*   few tiles that contain such rows (wave-uniform test).                                                                    */
+/* Chunks are <= 8192 rows (13-bit row field).                                                                                */
+/* ------------------------------------------------------------------------------------ */
+#define MX_PITCH 272
+#define MX_UNITS (MM_TILE * (MX_PITCH / 16))     /* 544 16-byte units per tile image */
+#define MX_DMAS ((MX_UNITS + 63) / 64)           /* 9 DMA instructions per tile */
+#define MX_BUF (MX_DMAS * 1024)
+#define MX_ROW_BITS 13
+#define MX_NONE (1 << 28)
+
+#ifndef MX_NBUF
+#define MX_NBUF 3 /* LDS ring: the DMA of a tile is issued MX_NBUF - 1 phases before the MFMAs that read it */
+#endif
+#ifndef MX_WAVES_PER_SIMD
+#define MX_WAVES_PER_SIMD 5
+#endif
+
+__device__ __forceinline__ void mx_select(const v16i &acc, uint32_t (&k1)[2], uint32_t (&k2)[2])
+{
+    /* two independent (best, second) chains per lane; they merge once, at the end */
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const uint32_t key = (uint32_t)acc[r];
+        const int c = r & 1;
+        k2[c] = min(max(k1[c], k2[c]), max(min(k1[c], k2[c]), key));
+        k1[c] = min(k1[c], key);
+    }
+}
+
+template <int N> __device__ __forceinline__ void mx_wait_vm()
+{
+    /* all but the N youngest vector-memory operations of this wave have completed (LDS-DMA included) */
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
+                                                       const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
+                                                       int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
+                                                       int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
+                                                       int th, int rnum, int rden, int out_stride,
+                                                       match_partial *__restrict__ partial, int32_t *__restrict__ idx_out,
+                                                       uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[MX_NBUF][MX_BUF];
+    /* 1-D grid, XCD-aware: every XCD gets a contiguous run of (frame, chunk, query block) triples, so the blocks that
+     * stream the same train rows share one L2 (dealt round-robin, the blocks of a frame would pull its 540 KB
+     * through all eight L2s) */
+    const int n_qblocks = (out_stride + 127) / 128;
+    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int qblock = logical % n_qblocks, chunk = (logical / n_qblocks) % n_chunks, frame = logical / (n_qblocks * n_chunks);
+    int tframe = frame + train_frame_shift;
+    if (tframe < 0) tframe = 0;
+    const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[tframe] : nt_fixed;
+    const bool excl = exclude_self_mode == 1 || (exclude_self_mode == 2 && tframe == frame);
+    const uint8_t *qf = query_x + (size_t)frame * q_frame_stride; /* strides in bytes: rows of 256 */
+    const uint8_t *tf = train_x + (size_t)tframe * t_frame_stride;
+    const int lane = lane_id(), col = lane & 31, half = lane >> 5;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int qbase = qblock * 128 + wave * 32; /* this wave's 32 queries: one B tile */
+    const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
+    const int n_tiles = qblock * 128 < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
+
+    /* source offsets of this lane's pieces inside a tile (the same for every tile): DMA m of the tile covers units
+     * 64 m .. 64 m + 63; wave w issues m = w, w + 4 (and w + 8 for wave 0) */
+    uint32_t src_off[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int u = imin(64 * (wave + 4 * k) + lane, MX_UNITS - 1);
+        const int r = u / (MX_PITCH / 16), j = imin(u - r * (MX_PITCH / 16), 15);
+        src_off[k] = (uint32_t)(r * 256 + j * 16);
+    }
+    /* every wave issues its DMAs for EVERY tile slot of the ring, also past the last tile (a harmless re-read of the
+     * last tile): the count of vector-memory operations in flight is then the same in every phase, which is what the
+     * counted waits below rely on */
+    auto dma_tile = [&](int tile) {
+#if defined(MX_EXP) && MX_EXP == 1 /* timing experiment: no DMA after the prologue */
+        if (tile >= MX_NBUF - 1) return;
+#endif
+#if defined(MX_EXP) && MX_EXP == 2 /* timing experiment: every DMA re-reads tile 0 (L2-hot) */
+        const int t = 0;
+#else
+        const int t = imin(tile, imax(n_tiles - 1, 0));
+#endif
+        const uint8_t *src = tf + (size_t)(c0 + t * MM_TILE) * 256;
+        uint8_t *dst = tiles[tile % MX_NBUF];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int m = wave + 4 * k;
+            if (m < MX_DMAS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + src_off[k]),
+                                                 (__attribute__((address_space(3))) void *)(dst + m * 1024), 16, 0, 0);
+        }
+    };
+    /* B fragments: k-step s, lane half h <-> bytes 32 s + 16 h .. + 15 of the query row, sign flipped */
+    v4i bq[8];
+    {
+        const int qi = qbase + col;
+        const uint8_t *qrow = qf + (size_t)(qi < nq ? qi : 0) * 256 + 16 * half;
+#pragma unroll
+        for (int sstep = 0; sstep < 8; sstep++) bq[sstep] = *(const v4i *)(qrow + 32 * sstep);
+    }
+    if (n_tiles > 0) {
+#pragma unroll
+        for (int t = 0; t < MX_NBUF - 1; t++) dma_tile(t);
+    }
+#pragma unroll
+    for (int sstep = 0; sstep < 8; sstep++) bq[sstep] = bq[sstep] ^ (int)0x80808080;
+    /* +32 everywhere: A0[m][0] = 4, B0[0][n] = 8, every other element 0 (k-slot 0 lives in byte 0 of lanes 0..31) */
+    const v4i a_step = v4i{half == 0 ? 4 : 0, 0, 0, 0}, b_step = v4i{half == 0 ? 8 : 0, 0, 0, 0};
+    v16i crow; /* accumulator input of the next tile: 2^20 + row index in the chunk */
+#pragma unroll
+    for (int r = 0; r < 16; r++) crow[r] = (1 << 20) + 4 * half + (r & 3) + 8 * (r >> 2);
+    const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
+    const int q_lo = qbase, q_hi = qbase + 32;
+    uint32_t k1[2], k2[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) k1[c] = k2[c] = 0xFFFFFFFFu;
+    /* Phase i: { wait: this wave's DMAs of tile i have landed (those of the MX_NBUF - 2 younger tiles may still fly) |
+     * barrier: so have everybody's, and everybody has finished reading tile i - 1 | refill tile i - 1's buffer with tile
+     * i + MX_NBUF - 1 | 8 + 1 MFMAs on tile i | selection }.  An LDS-DMA is a pending LDS write that only the issuing
+     * wave's vmcnt tracks; hipcc does not always count it when it places the waits of __syncthreads() (one loop barrier
+     * came out with lgkmcnt(0) only), hence the explicit counted waits and the raw barrier. */
+    for (int i = 0; i < n_tiles; i++) {
+#if defined(MX_EXP) && MX_EXP == 1
+        mx_wait_vm<0>();
+#else
+        if (wave == 0) mx_wait_vm<3 * (MX_NBUF - 2)>();
+        else mx_wait_vm<2 * (MX_NBUF - 2)>();
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_tile(i + MX_NBUF - 1);
+        if (!active) continue;
+        const int j0 = c0 + i * MM_TILE;
+        const uint8_t *arow = &tiles[i % MX_NBUF][col * MX_PITCH + 16 * half];
+        const bool masked = j0 + MM_TILE > c1 || (excl && j0 < q_hi && j0 + MM_TILE > q_lo);
+        v16i acc;
+        const v4i a0 = *(const v4i *)arow;
+        if (masked) {
+            const int rows_valid = c1 - j0, skip = excl ? qbase + col - j0 : -1;
+            v16i ci;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 4 * half + (r & 3) + 8 * (r >> 2);
+                ci[r] = crow[r] + ((row >= rows_valid || row == skip) ? MX_NONE : 0);
+            }
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], ci, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], crow, 0, 0, 0);
+        }
+#pragma unroll
+        for (int sstep = 1; sstep < 8; sstep++) {
+            const v4i a = *(const v4i *)(arow + 32 * sstep);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[sstep], acc, 0, 0, 0);
+        }
+        crow = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_step, b_step, crow, 0, 0, 0);
+        mx_select(acc, k1, k2);
+    }
+    mx_wait_vm<0>(); /* nothing of this block may still be writing LDS when the block retires */
+    /* fold the two chains of a lane, then lanes l and l + 32 (same query, different train rows) */
+    uint32_t f1 = min(k1[0], k1[1]), f2 = min(max(k1[0], k1[1]), min(k2[0], k2[1]));
+    const uint32_t o1 = (uint32_t)__shfl_xor((int)f1, 32, 64), o2 = (uint32_t)__shfl_xor((int)f2, 32, 64);
+    const uint32_t m1 = min(f1, o1), m2 = min(max(f1, o1), min(f2, o2));
+    const int qi = qbase + col;
+    if (half != 0 || qi >= out_stride) return;
+    const bool qvalid = qi < nq;
+    const int d1 = m1 >= (uint32_t)MX_NONE ? 0xFFFF : (int)(m1 >> MX_ROW_BITS); /* only excluded rows were seen: none */
+    const int d2 = m2 >= (uint32_t)MX_NONE ? 0xFFFF : (int)(m2 >> MX_ROW_BITS);
+    const int j1 = d1 == 0xFFFF ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1));
+    if (n_chunks > 1) {
+        match_partial mp;
+        mp.d1 = (uint16_t)d1;
+        mp.d2 = (uint16_t)d2;
+        mp.j1 = j1;
+        partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
+    } else {
+        const size_t o = (size_t)frame * out_stride + qi;
+        const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
+        idx_out[o] = ok ? j1 : -1;
+        d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+        d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__restrict__ partial, const int32_t *__restrict__ nq_arr,
                                                      int nq_fixed, int n_chunks, int th, int rnum, int rden, int out_stride,
                                                      int32_t *__restrict__ idx_out, uint16_t *__restrict__ d1_out,
@@ -2143,14 +2355,14 @@ void ssk_slots(hipStream_t s, const ss_geom *dg, const uint32_t *sel, const ss_l
 
 void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, const uint8_t *pyr, const uint8_t *blur,
                          const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
-                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma)
+                         uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma, uint8_t *desc_x)
 {
     if (steer_fma)
         hipLaunchKernelGGL(k_orient_describe<true>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
-                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride);
+                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
     else
         hipLaunchKernelGGL(k_orient_describe<false>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
-                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride);
+                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
 }
 
 /* which form of the matrix-core kernel: a single large database has the chip to itself (NU = 2), batches of frames share it */
@@ -2177,6 +2389,23 @@ int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_
     if (len < 4) len = 4;
     *chunk_len = len;
     return (int)(((long)n_train_max + len - 1) / len > 0 ? ((long)n_train_max + len - 1) / len : 1);
+}
+
+/* batch form on expanded descriptors (desc_x of the extraction): same arguments as ssk_match, strides in BYTES */
+void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
+                 int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
+                 int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
+                 uint16_t *d1, uint16_t *d2, int n_frames)
+{
+    dim3 grid(((out_stride + 127) / 128) * n_chunks * n_frames);
+    hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, th, rnum, rden, out_stride,
+                       (match_partial *)partial, idx, d1, d2);
+    if (n_chunks > 1) {
+        dim3 g2((out_stride + 255) / 256, n_frames);
+        hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, (const match_partial *)partial, nq_arr, nq_fixed, n_chunks, th, rnum,
+                           rden, out_stride, idx, d1, d2);
+    }
 }
 
 void ssk_match(hipStream_t s, const void *query, const void *train, const int32_t *nq_arr, const int32_t *nt_arr,
