@@ -59,11 +59,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+/* sum over the 64 lanes, returned uniform.  DPP row operations (no LDS round trips as __shfl_xor's ds_bpermute):
+ * two quad permutes and two mirrors leave every lane of a 16-lane row with the row's sum, two row broadcasts carry
+ * the rows' sums to lane 63 */
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  /* quad_perm [1,0,3,2] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  /* quad_perm [2,3,0,1] */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); /* row_half_mirror */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); /* row_mirror */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); /* row_bcast15 -> rows 1, 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); /* row_bcast31 -> rows 2, 3 */
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1466,6 +1473,29 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             }
         }
     }
+#ifndef OD_LDSWIN
+#define OD_LDSWIN 1
+#endif
+#if OD_LDSWIN
+    /* the rBRIEF taps land anywhere in the 37 x 37 blurred window around the keypoint (tap radius <= sqrt(338)): as
+     * global byte gathers, every one of a lane's 8 taps is a separate cache-line lookup in the CU's vector cache
+     * (~40 distinct lines per wave-instruction: the kernel was bound by that).  The window is independent of the angle,
+     * so it is staged now, with the IC patch: 37 rows x 10 aligned dwords, coalesced, one memory latency for both. */
+    __shared__ uint32_t win_all[4][37][10];
+    uint32_t(*win)[10] = win_all[threadIdx.x >> 6];
+    const int wx0 = (kx - 18) & ~3;
+    {
+        const uint8_t *b0 = blur + fb + (size_t)(ky - 18) * pitch + wx0;
+#pragma unroll
+        for (int it = 0; it < 6; it++) { /* 370 dwords */
+            const int idx = lane + WAVE * it;
+            if (idx < 37 * 10) {
+                const int r = idx / 10, c = idx - r * 10;
+                win[r][c] = *(const uint32_t *)(b0 + (__umul24((uint32_t)r, (uint32_t)pitch) + 4u * (uint32_t)c));
+            }
+        }
+    }
+#endif
     wave_sync();
     int m10, m01;
     {
@@ -1500,7 +1530,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
      * v_mad_i32_i24 per sample address */
     constexpr float RN_MAGIC = 8388640.f;
     constexpr int RN_BIAS = 0x4B000020;
+#if OD_LDSWIN
+    /* byte index in the staged window: (18 + row) * 40 + (kx - wx0) + col, with row / col still carrying their biases */
+    const uint8_t *center = (const uint8_t *)&win[0][0];
+    const uint32_t kbias = (uint32_t)((18 - 32) * 40 + (kx - wx0)) - (uint32_t)RN_BIAS;
+    const int pitch_t = 40;
+#else
     const uint8_t *center = blur + fb + (size_t)ky * pitch + kx - RN_BIAS - 32 * pitch;
+    const uint32_t kbias = 0;
+    const int pitch_t = pitch;
+#endif
     uint32_t off0[4], off1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -1515,8 +1554,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
         const int c0 = __float_as_int(__fadd_rn(fc0, RN_MAGIC));
         const int r1 = __float_as_int(__fadd_rn(fr1, RN_MAGIC));
         const int c1 = __float_as_int(__fadd_rn(fc1, RN_MAGIC));
-        off0[k] = (uint32_t)(__mul24(r0, pitch) + c0); /* (32 + row) * pitch + RN_BIAS + col: positive, below 2^31 */
-        off1[k] = (uint32_t)(__mul24(r1, pitch) + c1);
+        off0[k] = (uint32_t)(__mul24(r0, pitch_t) + c0) + kbias; /* (32 + row) * pitch + RN_BIAS + col: positive, below 2^31 */
+        off1[k] = (uint32_t)(__mul24(r1, pitch_t) + c1) + kbias;
     }
     int t0[4], t1[4];
 #pragma unroll
