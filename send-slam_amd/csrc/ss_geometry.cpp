@@ -128,6 +128,12 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
             const int row = lane & 31, half = lane >> 5;
             int count = 0;
             g->ic_u0[lane] = 0;
+            for (int k = 0; k < 4; k++) {
+                static const int8_t pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
+                uint32_t word = 0;
+                for (int b = 0; b < 4; b++) word |= (uint32_t)(uint8_t)pattern[4 * (lane + 64 * k) + b] << (8 * b);
+                g->pat4[lane][k] = word;
+            }
             if (row <= 2 * SS_HALF_PATCH) {
                 const int d = g->umax[row < SS_HALF_PATCH ? SS_HALF_PATCH - row : row - SS_HALF_PATCH];
                 count = half ? d + 1 : d;

@@ -1416,15 +1416,20 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
 /* pairs L, L+64, L+128, L+192; __ballot(t0 < t1) IS descriptor bytes 8k .. 8k+7 (bit i of  */
 /* byte j = test 8j+i).                                                                    */
 /* ------------------------------------------------------------------------------------ */
-static_assert(offsetof(ss_geom, ic_mask) % 16 == 0, "ic_mask is loaded as dwordx4");
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {SS_BIT_PATTERN_31_VALUES};
+static_assert(offsetof(ss_geom, ic_mask) % 16 == 0 && offsetof(ss_geom, pat4) % 16 == 0, "ic_mask and pat4 are loaded as dwordx4");
 
 /* STEER_FMA: how the rotated tap coordinates cvRound(x*b + y*a), cvRound(x*a - y*b) are evaluated.  false = two
  * products and one sum, each rounded (the C expression as written); true = what GCC's FMA contraction makes of it
  * when upstream is built -O3 -march=native (CMakeLists.txt:10-13): the FIRST product fused into the sum,
  * fma(x, b, y*a) and fma(x, a, -(y*b)).  Which one the reference binary runs is machine- and compiler-dependent and
- * unpinned (tests/golden/ref_dump/README.md); both are implemented and tested against the oracle's two forms. */
-template <bool STEER_FMA>
+ * unpinned (tests/golden/ref_dump/README.md); both are implemented and tested against the oracle's two forms.
+ * KP keypoints per wave, side by side: a keypoint is a chain of dependent memory round trips (reference record ->
+ * level geometry -> patch + window -> LDS) with little arithmetic in between, so a wave that walks two chains at once
+ * keeps twice the bytes in flight for the same lifetime (the loads of both are issued together, stage by stage). */
+#ifndef OD_KP
+#define OD_KP 1 /* measured in the four-context pipeline: 1 -> 93.5-95.4 k frames/s, 2 -> 92.5 k (twice the LDS per block) */
+#endif
+template <bool STEER_FMA, int KP>
 __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur,
                                                          const uint32_t *__restrict__ sel,
@@ -1437,74 +1442,88 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     /* all blocks of a frame on one XCD: keypoints whose patches share 64-B lines then share an L2 */
     const int logical = xcd_remap((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
     const int frame = logical / (int)gridDim.x;
-    const int slot = rfl((logical - frame * (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6));
-    if (slot >= n_kp[frame]) return;
+    const int slot0 = rfl(((logical - frame * (int)gridDim.x) * 4 + (int)(threadIdx.x >> 6)) * KP);
+    const int n_frame = n_kp[frame];
+    if (slot0 >= n_frame) return;
     const int lane = lane_id();
-    const uint2 ref = ((const uint2 *)kp_ref)[(size_t)frame * g->kcap + slot]; /* k_slots left the record next to its
-                                                                               * reference: one load, not two in a row */
-    const int level = (int)(ref.x >> 16);
-    const ss_level &L = g->lv[level];
-    const uint32_t rec = ref.y;
-    const int kx = SS_PX(rec), ky = SS_PY(rec), resp = SS_PR(rec);
-    const size_t fb = (size_t)frame * g->block_bytes + L.off;
-    const int pitch = L.pitch;
-
-    /* IC_Angle: the 31-row patch around the keypoint is staged in LDS as aligned dwords
-     * (5 coalesced loads per lane instead of 16 byte gathers); lane = (row, half) of the disc */
-    __shared__ uint32_t patch_all[4][31][10];
-    uint32_t(*patch)[10] = patch_all[threadIdx.x >> 6];
-    const int px0 = (kx - SS_HALF_PATCH) & ~3; /* >= 4: keypoints stay 19 px inside the level */
-    uint32_t pat[4]; /* this lane's four sample pairs of the pattern: independent of the keypoint, requested first */
+    const int kcap = g->kcap;
+    /* IC_Angle: the 31-row patch around the keypoint is staged in LDS as aligned dwords (5 coalesced loads per lane
+     * instead of 16 byte gathers); lane = (row, half) of the disc.  The rBRIEF taps land anywhere in the 37 x 37 blurred
+     * window around the keypoint (tap radius <= sqrt(338)): as global byte gathers, every one of a lane's 8 taps was a
+     * separate cache-line lookup in the CU's vector cache (~40 distinct lines per wave-instruction: the kernel was bound
+     * by that).  The window does not depend on the angle, so it is staged with the patch: 37 rows x 10 aligned dwords,
+     * coalesced, one memory latency for both. */
+    /* 16-byte pieces: the texture addresser, which takes 64 lane addresses per load instruction whatever their width,
+     * was the busiest unit of this kernel with dword loads (TA_BUSY 75 %); a row of the patch is 3 pieces from the
+     * 16-byte boundary at or below kx - 15, a row of the window 4 pieces from the one at or below kx - 18 */
+    __shared__ __attribute__((aligned(16))) uint32_t patch_all[4][KP][31 * 12 + 4]; /* + 4: the last row's masked-off tail read */
+    __shared__ __attribute__((aligned(16))) uint32_t win_all[4][KP][37 * 16];
+    int slot[KP], level[KP], kx[KP], ky[KP], resp[KP], pitch[KP], px0[KP], wx0[KP];
+    size_t fb[KP];
+    uint2 ref[KP];
 #pragma unroll
-    for (int k = 0; k < 4; k++) pat[k] = *(const uint32_t *)(c_pattern + 4 * (lane + 64 * k));
+    for (int k = 0; k < KP; k++) {
+        slot[k] = slot0 + k < n_frame ? slot0 + k : slot0; /* an odd count: the last wave walks its keypoint twice, writes it once */
+        ref[k] = ((const uint2 *)kp_ref)[(size_t)frame * kcap + slot[k]]; /* k_slots left the record next to its reference */
+    }
+    /* this lane's four sample pairs of the pattern: independent of the keypoint, requested first */
+    const uint4 pat4 = ((const uint4 *)g->pat4)[lane];
+    const uint32_t pat[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
     /* this lane's share of the disc (row lane & 31, left or right half): first u and the byte masks of its <= 16 pixels */
     const uint4 icm = ((const uint4 *)g->ic_mask)[lane];
     const int u0 = g->ic_u0[lane];
-    {
-        const bool inplace = level == 0 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
-        const int ipitch = inplace ? lvl0_pitch : pitch;
-        const uint8_t *p0 = (inplace ? lvl0 + (int64_t)frame * lvl0_fs : pyr + fb) + (size_t)(ky - SS_HALF_PATCH) * ipitch + px0;
 #pragma unroll
-        for (int it = 0; it < 5; it++) { /* 310 dwords = 4 full rounds of the wave + 54 lanes */
+    for (int k = 0; k < KP; k++) {
+        level[k] = rfl((int)(ref[k].x >> 16));
+        const ss_level &L = g->lv[level[k]];
+        const uint32_t rec = (uint32_t)rfl((int)ref[k].y);
+        kx[k] = SS_PX(rec);
+        ky[k] = SS_PY(rec);
+        resp[k] = SS_PR(rec);
+        fb[k] = (size_t)frame * g->block_bytes + L.off;
+        pitch[k] = L.pitch;
+        px0[k] = (kx[k] - SS_HALF_PATCH) & ~15; /* >= 0: keypoints stay 19 px inside the level */
+        wx0[k] = (kx[k] - 18) & ~15;
+    }
+    uint4 pv[KP][2], wv[KP][3];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const bool inplace = level[k] == 0 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
+        const int ipitch = inplace ? lvl0_pitch : pitch[k];
+        const uint8_t *p0 = (inplace ? lvl0 + (int64_t)frame * lvl0_fs : pyr + fb[k]) + (size_t)(ky[k] - SS_HALF_PATCH) * ipitch + px0[k];
+        const uint8_t *b0 = blur + fb[k] + (size_t)(ky[k] - 18) * pitch[k] + wx0[k];
+#pragma unroll
+        for (int it = 0; it < 2; it++) { /* 31 rows x 3 pieces = 93 */
             const int idx = lane + WAVE * it;
-            if (idx < 31 * 10) {
-                const int r = idx / 10, c = idx - r * 10;
-                patch[r][c] = *(const uint32_t *)(p0 + (__umul24((uint32_t)r, (uint32_t)ipitch) + 4u * (uint32_t)c));
-            }
+            const int r = idx / 3, c = idx - r * 3;
+            pv[k][it] = idx < 31 * 3 ? *(const uint4 *)(p0 + (__umul24((uint32_t)r, (uint32_t)ipitch) + 16u * (uint32_t)c)) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; it++) { /* 37 rows x 4 pieces = 148 */
+            const int idx = lane + WAVE * it;
+            wv[k][it] = idx < 37 * 4 ? *(const uint4 *)(b0 + (__umul24((uint32_t)(idx >> 2), (uint32_t)pitch[k]) + 16u * (uint32_t)(idx & 3))) : make_uint4(0, 0, 0, 0);
         }
     }
-#ifndef OD_LDSWIN
-#define OD_LDSWIN 1
-#endif
-#if OD_LDSWIN
-    /* the rBRIEF taps land anywhere in the 37 x 37 blurred window around the keypoint (tap radius <= sqrt(338)): as
-     * global byte gathers, every one of a lane's 8 taps is a separate cache-line lookup in the CU's vector cache
-     * (~40 distinct lines per wave-instruction: the kernel was bound by that).  The window is independent of the angle,
-     * so it is staged now, with the IC patch: 37 rows x 10 aligned dwords, coalesced, one memory latency for both. */
-    __shared__ uint32_t win_all[4][37][10];
-    uint32_t(*win)[10] = win_all[threadIdx.x >> 6];
-    const int wx0 = (kx - 18) & ~3;
-    {
-        const uint8_t *b0 = blur + fb + (size_t)(ky - 18) * pitch + wx0;
 #pragma unroll
-        for (int it = 0; it < 6; it++) { /* 370 dwords */
-            const int idx = lane + WAVE * it;
-            if (idx < 37 * 10) {
-                const int r = idx / 10, c = idx - r * 10;
-                win[r][c] = *(const uint32_t *)(b0 + (__umul24((uint32_t)r, (uint32_t)pitch) + 4u * (uint32_t)c));
-            }
-        }
+    for (int k = 0; k < KP; k++) {
+        uint4 *pl = (uint4 *)&patch_all[threadIdx.x >> 6][k][0], *wl = (uint4 *)&win_all[threadIdx.x >> 6][k][0];
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+            if (lane + WAVE * it < 31 * 3) pl[lane + WAVE * it] = pv[k][it];
+#pragma unroll
+        for (int it = 0; it < 3; it++)
+            if (lane + WAVE * it < 37 * 4) wl[lane + WAVE * it] = wv[k][it];
     }
-#endif
     wave_sync();
-    int m10, m01;
-    {
+    int m10[KP], m01[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
         /* the lane's pixels are 16 consecutive bytes of its staged row starting at u0 (the tail masked off): five
          * aligned dwords, four v_alignbyte, then m10 = sum u * I = u0 * sum I + sum k * I_k and m01 = v * sum I as
          * eight v_dot4_u32_u8 -- integer sums, so the order of additions is free */
         const int row = imin(lane & 31, 30); /* lanes 31 and 63 carry zero masks */
-        const int sb = (kx - px0) + u0;      /* 0 .. 18: byte offset in the staged row */
-        const uint32_t *rw = &patch[row][sb >> 2];
+        const int sb = (kx[k] - px0[k]) + u0; /* 0 .. 30: byte offset in the staged row */
+        const uint32_t *rw = &patch_all[threadIdx.x >> 6][k][row * 12 + (sb >> 2)];
         const uint32_t sh = (uint32_t)sb & 3u;
         const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3], w4 = rw[4];
         const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh) & icm.x, a1 = __builtin_amdgcn_alignbyte(w2, w1, sh) & icm.y;
@@ -1513,87 +1532,111 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
                             __builtin_amdgcn_udot4(a2, 0x01010101u, __builtin_amdgcn_udot4(a3, 0x01010101u, 0u, false), false), false), false);
         const uint32_t ws = __builtin_amdgcn_udot4(a0, 0x03020100u, __builtin_amdgcn_udot4(a1, 0x07060504u,
                             __builtin_amdgcn_udot4(a2, 0x0B0A0908u, __builtin_amdgcn_udot4(a3, 0x0F0E0D0Cu, 0u, false), false), false), false);
-        m10 = __mul24(u0, (int)rs) + (int)ws;
-        m01 = __mul24((lane & 31) - SS_HALF_PATCH, (int)rs);
+        m10[k] = __mul24(u0, (int)rs) + (int)ws;
+        m01[k] = __mul24((lane & 31) - SS_HALF_PATCH, (int)rs);
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = ss_fast_atan2((float)m01, (float)m10);
-    float b, a;
-    ss_sincosf_deg(angle, &b, &a);
+    float angle[KP], sb_[KP], ca_[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        m10[k] = wave_sum(m10[k]);
+        m01[k] = wave_sum(m01[k]);
+    }
+    {
+        /* fastAtan2 and the double-precision sine / cosine are the same for all 64 lanes of a keypoint: lane k evaluates
+         * them for keypoint k, so the wave pays for ONE evaluation however many keypoints it walks */
+        int vm01 = m01[0], vm10 = m10[0];
+#pragma unroll
+        for (int k = 1; k < KP; k++) {
+            vm01 = lane == k ? m01[k] : vm01;
+            vm10 = lane == k ? m10[k] : vm10;
+        }
+        const float ang_v = ss_fast_atan2((float)vm01, (float)vm10);
+        float sin_v, cos_v;
+        ss_sincosf_deg(ang_v, &sin_v, &cos_v);
+#pragma unroll
+        for (int k = 0; k < KP; k++) {
+            angle[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ang_v), k));
+            sb_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sin_v), k));
+            ca_[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cos_v), k));
+        }
+    }
 
-    /* steered rBRIEF: the eight sample addresses of a lane first, then the eight byte loads together, then the
+    /* steered rBRIEF: the eight sample addresses of a lane first, then the eight byte reads together, then the
      * four ballots (the pattern words were requested before the IC stage) */
     /* cvRound without v_rndne + v_cvt: x + (2^23 + 32) has ulp 1, so the sum is the integer nearest to x (ties to even,
      * like cvRound) and its bits are 0x4B000020 + round(x) for |x| <= 32.  The low 24 bits, 32 + round(x), are what the
-     * 24-bit multiplier reads, and both biases move into the (wave-uniform) base pointer: two additions and one
-     * v_mad_i32_i24 per sample address */
+     * 24-bit multiplier reads; the biases move into one wave-uniform constant: byte index in the staged window =
+     * (18 + row) * 64 + (kx - wx0) + col */
     constexpr float RN_MAGIC = 8388640.f;
     constexpr int RN_BIAS = 0x4B000020;
-#if OD_LDSWIN
-    /* byte index in the staged window: (18 + row) * 40 + (kx - wx0) + col, with row / col still carrying their biases */
-    const uint8_t *center = (const uint8_t *)&win[0][0];
-    const uint32_t kbias = (uint32_t)((18 - 32) * 40 + (kx - wx0)) - (uint32_t)RN_BIAS;
-    const int pitch_t = 40;
-#else
-    const uint8_t *center = blur + fb + (size_t)ky * pitch + kx - RN_BIAS - 32 * pitch;
-    const uint32_t kbias = 0;
-    const int pitch_t = pitch;
-#endif
-    uint32_t off0[4], off1[4];
+    uint32_t off0[KP][4], off1[KP][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t pt = pat[k]; /* x0 y0 x1 y1 as int8 */
-        const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
-        const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
-        const float fr0 = STEER_FMA ? __fmaf_rn(x0, b, __fmul_rn(y0, a)) : __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
-        const float fc0 = STEER_FMA ? __fmaf_rn(x0, a, -__fmul_rn(y0, b)) : __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
-        const float fr1 = STEER_FMA ? __fmaf_rn(x1, b, __fmul_rn(y1, a)) : __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
-        const float fc1 = STEER_FMA ? __fmaf_rn(x1, a, -__fmul_rn(y1, b)) : __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
-        const int r0 = __float_as_int(__fadd_rn(fr0, RN_MAGIC));
-        const int c0 = __float_as_int(__fadd_rn(fc0, RN_MAGIC));
-        const int r1 = __float_as_int(__fadd_rn(fr1, RN_MAGIC));
-        const int c1 = __float_as_int(__fadd_rn(fc1, RN_MAGIC));
-        off0[k] = (uint32_t)(__mul24(r0, pitch_t) + c0) + kbias; /* (32 + row) * pitch + RN_BIAS + col: positive, below 2^31 */
-        off1[k] = (uint32_t)(__mul24(r1, pitch_t) + c1) + kbias;
-    }
-    int t0[4], t1[4];
+    for (int k = 0; k < KP; k++) {
+        const float b = sb_[k], a = ca_[k];
+        const uint32_t kbias = (uint32_t)((18 - 32) * 64 + (kx[k] - wx0[k])) - (uint32_t)RN_BIAS;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        t0[k] = center[off0[k]];
-        t1[k] = center[off1[k]];
-    }
-    uint64_t words[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) words[k] = __ballot(t0[k] < t1[k]);
-    if (desc_x) {
-        /* the same 256 bits as bytes: bit b of the descriptor -> byte b = +64 (set) / -64 (clear).  k_match_mfma_x reads
-         * these rows as i8 MFMA operands (the dot product of a row with a sign-flipped row is 8192 * hamming - 2^20)
-         * without expanding anything in its loop.  Lane L writes bytes 4 L .. 4 L + 3 = bits 4 L .. 4 L + 3: one coalesced
-         * 256-byte store per wave.  Nibble -> four 0 / 1 bytes by one multiplication, then 0 -> 0xC0, 1 -> 0x40. */
-        const uint64_t wsel = lane < 16 ? words[0] : lane < 32 ? words[1] : lane < 48 ? words[2] : words[3];
-        const uint32_t nib = (uint32_t)(wsel >> (4 * (lane & 15))) & 15u;
-        const uint32_t b01 = (nib * 0x00204081u) & 0x01010101u;
-        *(uint32_t *)(desc_x + ((size_t)frame * g->kcap + slot) * 256 + 4 * lane) = 0xC0C0C0C0u ^ (b01 << 7);
-    }
-    if (lane == 0) {
-        uint64_t *d = (uint64_t *)(desc + ((size_t)frame * g->kcap + slot) * SS_DESC_BYTES);
-        d[0] = words[0];
-        d[1] = words[1];
-        d[2] = words[2];
-        d[3] = words[3];
-        ss_keypoint kp;
-        kp.x = (float)kx;
-        kp.y = (float)ky;
-        if (level != 0) {
-            kp.x = __fmul_rn(kp.x, L.scale);
-            kp.y = __fmul_rn(kp.y, L.scale);
+        for (int q = 0; q < 4; q++) {
+            const uint32_t pt = pat[q]; /* x0 y0 x1 y1 as int8 */
+            const float x0 = (float)(int8_t)(pt & 0xFF), y0 = (float)(int8_t)((pt >> 8) & 0xFF);
+            const float x1 = (float)(int8_t)((pt >> 16) & 0xFF), y1 = (float)(int8_t)(pt >> 24);
+            const float fr0 = STEER_FMA ? __fmaf_rn(x0, b, __fmul_rn(y0, a)) : __fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a));
+            const float fc0 = STEER_FMA ? __fmaf_rn(x0, a, -__fmul_rn(y0, b)) : __fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b));
+            const float fr1 = STEER_FMA ? __fmaf_rn(x1, b, __fmul_rn(y1, a)) : __fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a));
+            const float fc1 = STEER_FMA ? __fmaf_rn(x1, a, -__fmul_rn(y1, b)) : __fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b));
+            const int r0 = __float_as_int(__fadd_rn(fr0, RN_MAGIC));
+            const int c0 = __float_as_int(__fadd_rn(fc0, RN_MAGIC));
+            const int r1 = __float_as_int(__fadd_rn(fr1, RN_MAGIC));
+            const int c1 = __float_as_int(__fadd_rn(fc1, RN_MAGIC));
+            off0[k][q] = (uint32_t)(__mul24(r0, 64) + c0) + kbias;
+            off1[k][q] = (uint32_t)(__mul24(r1, 64) + c1) + kbias;
         }
-        kp.size = (float)L.scaled_patch;
-        kp.angle = angle;
-        kp.response = (float)resp;
-        kp.octave = level;
-        kps[(size_t)frame * g->kcap + slot] = kp;
+    }
+    int t0[KP][4], t1[KP][4];
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        const uint8_t *center = (const uint8_t *)&win_all[threadIdx.x >> 6][k][0];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            t0[k][q] = center[off0[k][q]];
+            t1[k][q] = center[off1[k][q]];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+        if (k > 0 && slot0 + k >= n_frame) break; /* the duplicate of an odd tail is not written */
+        uint64_t words[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) words[q] = __ballot(t0[k][q] < t1[k][q]);
+        if (desc_x) {
+            /* the same 256 bits as bytes: bit b of the descriptor -> byte b = +64 (set) / -64 (clear).  k_match_mfma_x reads
+             * these rows as i8 MFMA operands (the dot product of a row with a sign-flipped row is 8192 * hamming - 2^20)
+             * without expanding anything in its loop.  Lane L writes bytes 4 L .. 4 L + 3 = bits 4 L .. 4 L + 3: one
+             * coalesced 256-byte store per wave.  Nibble -> four 0 / 1 bytes by one multiplication, then 0 -> 0xC0, 1 -> 0x40. */
+            const uint64_t wsel = lane < 16 ? words[0] : lane < 32 ? words[1] : lane < 48 ? words[2] : words[3];
+            const uint32_t nib = (uint32_t)(wsel >> (4 * (lane & 15))) & 15u;
+            const uint32_t b01 = (nib * 0x00204081u) & 0x01010101u;
+            *(uint32_t *)(desc_x + ((size_t)frame * kcap + slot[k]) * 256 + 4 * lane) = 0xC0C0C0C0u ^ (b01 << 7);
+        }
+        if (lane == 0) {
+            const ss_level &L = g->lv[level[k]];
+            uint64_t *d = (uint64_t *)(desc + ((size_t)frame * kcap + slot[k]) * SS_DESC_BYTES);
+            d[0] = words[0];
+            d[1] = words[1];
+            d[2] = words[2];
+            d[3] = words[3];
+            ss_keypoint kp;
+            kp.x = (float)kx[k];
+            kp.y = (float)ky[k];
+            if (level[k] != 0) {
+                kp.x = __fmul_rn(kp.x, L.scale);
+                kp.y = __fmul_rn(kp.y, L.scale);
+            }
+            kp.size = (float)L.scaled_patch;
+            kp.angle = angle[k];
+            kp.response = (float)resp[k];
+            kp.octave = level[k];
+            kps[(size_t)frame * kcap + slot[k]] = kp;
+        }
     }
 }
 
@@ -2396,12 +2439,13 @@ void ssk_orient_describe(hipStream_t s, const ss_geom *dg, const ss_geom &hg, co
                          const uint32_t *sel, const uint32_t *kp_ref, const int32_t *n_kp, ss_keypoint *kps,
                          uint8_t *desc, int n_frames, const ss_lvl0 &l0, bool steer_fma, uint8_t *desc_x)
 {
+    /* kcap is a multiple of 64: kcap / (4 waves x OD_KP keypoints) blocks per frame */
     if (steer_fma)
-        hipLaunchKernelGGL(k_orient_describe<true>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
-                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
+        hipLaunchKernelGGL((k_orient_describe<true, OD_KP>), dim3(hg.kcap / (4 * OD_KP), n_frames), dim3(256), 0, s, dg, pyr, blur, sel,
+                           kp_ref, n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
     else
-        hipLaunchKernelGGL(k_orient_describe<false>, dim3(hg.kcap / 4, n_frames), dim3(256), 0, s, dg, pyr, blur, sel, kp_ref,
-                           n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
+        hipLaunchKernelGGL((k_orient_describe<false, OD_KP>), dim3(hg.kcap / (4 * OD_KP), n_frames), dim3(256), 0, s, dg, pyr, blur, sel,
+                           kp_ref, n_kp, kps, desc, l0.ptr, l0.pitch, l0.frame_stride, desc_x);
 }
 
 /* which form of the matrix-core kernel: a single large database has the chip to itself (NU = 2), batches of frames share it */

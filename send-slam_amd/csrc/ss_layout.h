@@ -95,6 +95,9 @@ typedef struct {
     int32_t ic_pad[2];       /* keeps ic_mask 16-byte aligned (loaded as dwordx4) */
     uint32_t ic_mask[64][4];
     int32_t ic_u0[64];
+    /* rBRIEF pattern re-laid per lane: lane L owns test pairs L, 64 + L, 128 + L, 192 + L (x0 y0 x1 y1 as int8 each):
+     * one dwordx4 load per lane instead of four dword loads */
+    uint32_t pat4[64][4];
     ss_level lv[SS_MAX_LEVELS_];
 } ss_geom;
 

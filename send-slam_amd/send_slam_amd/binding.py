@@ -102,9 +102,11 @@ _lib = None
 
 def load():
     """Loads the shared library or raises; never substitutes anything for it."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("SENDSLAM_LIB"):  # A/B builds of the same ABI (profiles/tools/*.sh); never a fallback
+        LIB_PATH = os.environ["SENDSLAM_LIB"]
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C send-slam_amd` "
                           f"(or __graft_entry__.build()); there is no CPU fallback")
