@@ -692,7 +692,7 @@ def main():
                         "isolated_GBps": None if not im or not s["algorithmic_bytes"] else round(s["algorithmic_bytes"] / (im * 1e-3) / 1e9, 1)})
     with_bytes = [k for k in kernels if k["achieved_GBps"] is not None]
     dom = max(with_bytes, key=lambda k: (k["isolated_mean_ms"] or k["mean_ms"]) * k["launches"]) if with_bytes else None
-    stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match_mfma", "orient_describe": "k_orient_describe", "resize": "k_resize_lds"}
+    stage_kernel = {"fast_blur_nms": "k_fast_score", "match": "k_match_mfma_x", "orient_describe": "k_orient_describe", "resize": "k_resize_lds"}
     prof = {}
     ppath = os.path.join(ROOT, "profiles", "per_frame_counters.json")
     if os.path.exists(ppath):
