@@ -185,8 +185,15 @@ def bench_loop_closure(a):
     out = (torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, dtype=torch.int16, device=dev),
            torch.empty(nq, dtype=torch.int16, device=dev))
     steps = a.steps if a.steps else 20
+    # the keyframe database is static: its slab is expanded once to the matrix-core matcher's operand format (256 B per
+    # descriptor: 5.1 GB for the whole database, 640 MB per GPU at 8); SENDSLAM_LC_PACKED=1 keeps the packed rows and
+    # the expanding kernel (k_match_mfma<2>) instead
+    dbx = None if os.environ.get("SENDSLAM_LC_PACKED") == "1" else multi.expand_database(ctx, db)
+    kw = {} if dbx is None else {"db_expanded": dbx, "n_db": e - b}
+    _q = multi.loop_closure_query_device
+    multi_query = lambda: _q(ctx, query, db, b, out=out, **kw)  # noqa: E731
     for _ in range(max(a.warmup, 1)):
-        multi.loop_closure_query_device(ctx, query, db, b, out=out)
+        multi_query()
     ctx.synchronize()
     ctx.profile(True)
     ctx.profile_reset()
@@ -195,7 +202,7 @@ def bench_loop_closure(a):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        multi.loop_closure_query_device(ctx, query, db, b, out=out)
+        multi_query()
     ctx.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -209,7 +216,7 @@ def bench_loop_closure(a):
         roof = None
         if mk and mk["mean_ms"] > 0:
             t = mk["mean_ms"] * 1e-3
-            roof = {"kernel": "match (k_match_mfma<2> + merge, this rank's slab)", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
+            roof = {"kernel": ("match (k_match_mfma<2>" if dbx is None else "match (k_match_mfma_x on the expanded slab") + " + merge, this rank's slab)", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
                     "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
                     "kernel_ms": round(mk["mean_ms"], 4), "traffic": None}
         print(json.dumps({
@@ -218,7 +225,8 @@ def bench_loop_closure(a):
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
-                                   "raw local match -> 8-byte records, all_gather, fold kernel", "parallelism": f"db slabs x {world}"},
+                                   "raw local match -> 8-byte records, all_gather, fold kernel", "parallelism": f"db slabs x {world}",
+                       "database_format": "packed 32 B rows" if dbx is None else "expanded once to 256 B rows (matrix-core operand)"},
             "roofline": roof, "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
             "pairs_per_s": float(f"{nq * n_db * steps / elapsed:.4g}")}))
     ctx.close()

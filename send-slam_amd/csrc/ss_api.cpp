@@ -764,8 +764,45 @@ int ss_track_features(ss_ctx *c, int camera_id, double timestamp, const void *d_
     return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, keypoints, n_keypoints, out);
 }
 
-int ss_match_partial_device(ss_ctx *c, const void *d_query, int n_query, const void *d_train, int n_train, int64_t row_offset,
-                            void *d_part)
+int ss_expand_descriptors_device(ss_ctx *c, const void *d_packed, int n, void *d_expanded)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n < 0) return fail(c, SS_ERR_INVALID_ARG, "bad descriptor count");
+    if (n == 0) return SS_OK;
+    if (!d_packed || !d_expanded) return fail(c, SS_ERR_INVALID_ARG, "NULL descriptor buffer");
+    stage_timer t(c, "expand", (int64_t)n * (32 + 256));
+    ssk_expand_desc(c->stream, d_packed, n, d_expanded);
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+int ss_match_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, const void *d_train_x, int n_train, int th, int ratio_num,
+                             int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_query < 0 || n_train < 0 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
+    if (n_query == 0) return SS_OK;
+    if (!d_query_x || (!d_train_x && n_train > 0) || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    int chunk_len = 32;
+    const int n_chunks = ssk_match_x_chunks(n_query, std::max(n_train, 1), &chunk_len);
+    if (n_chunks > 1) {
+        int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_chunks * n_query * SSK_MATCH_PARTIAL_BYTES);
+        if (rc != SS_OK) return rc;
+    }
+    {
+        stage_timer t(c, "match", (int64_t)n_query * 256 + (int64_t)n_train * 256 + (int64_t)n_query * 8);
+        ssk_match_x_single(c->stream, (const uint8_t *)d_query_x, n_query, (const uint8_t *)(d_train_x ? d_train_x : d_query_x), n_train,
+                           chunk_len, n_chunks, exclude_self, th, ratio_num, ratio_den, c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1,
+                           (uint16_t *)d_d2);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
+static int partial_common(ss_ctx *c, bool expanded, const void *d_query, int n_query, const void *d_train, int n_train,
+                          int64_t row_offset, void *d_part)
 {
     if (!c) return SS_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
@@ -777,11 +814,24 @@ int ss_match_partial_device(ss_ctx *c, const void *d_query, int n_query, const v
     if (rc != SS_OK) return rc;
     int32_t *di = (int32_t *)c->d_part_tmp;
     uint16_t *dd1 = (uint16_t *)(c->d_part_tmp + (size_t)n_query * 4), *dd2 = (uint16_t *)(c->d_part_tmp + (size_t)n_query * 6);
-    rc = ss_match_device(c, d_query, n_query, d_train, n_train, -1, 1, 1, 0, di, dd1, dd2);
+    rc = expanded ? ss_match_expanded_device(c, d_query, n_query, d_train, n_train, -1, 1, 1, 0, di, dd1, dd2)
+                  : ss_match_device(c, d_query, n_query, d_train, n_train, -1, 1, 1, 0, di, dd1, dd2);
     if (rc != SS_OK) return rc;
     ssk_pack_partial(c->stream, di, dd1, dd2, n_query, (int32_t)row_offset, d_part);
     HIP_TRY(c, hipGetLastError());
     return SS_OK;
+}
+
+int ss_match_partial_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, const void *d_train_x, int n_train,
+                                     int64_t row_offset, void *d_part)
+{
+    return partial_common(c, true, d_query_x, n_query, d_train_x, n_train, row_offset, d_part);
+}
+
+int ss_match_partial_device(ss_ctx *c, const void *d_query, int n_query, const void *d_train, int n_train, int64_t row_offset,
+                            void *d_part)
+{
+    return partial_common(c, false, d_query, n_query, d_train, n_train, row_offset, d_part);
 }
 
 int ss_match_fold_device(ss_ctx *c, const void *d_parts, int n_parts, int n_query, int th, int ratio_num, int ratio_den,

@@ -59,6 +59,12 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
                  int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
                  int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
                  uint16_t *d1, uint16_t *d2, int n_frames);
+/* packed 32-B descriptors -> expanded 256-B rows; `out` holds n rounded up to 32 rows */
+void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out);
+/* one expanded query set against one expanded train set (any size): chunk plan + launch (+ merge of the chunk partials) */
+int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len);
+void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uint8_t *train_x, int nt, int chunk_len, int n_chunks,
+                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2);
 /* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8

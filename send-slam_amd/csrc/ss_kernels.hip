@@ -2227,6 +2227,22 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
     d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
 }
 
+/* packed descriptors (32 B) -> the matrix-core matcher's operand rows (256 B: bit b -> byte b = +64 / -64), the same
+ * format k_orient_describe writes for the frames of a batch.  One wave per row, one coalesced 256-byte store; rows
+ * n .. n_alloc - 1 (n_alloc = n rounded up to the 32-row tile) are zero-filled: they contribute 0 and are masked anyway. */
+__global__ __launch_bounds__(256) void k_expand_desc(const uint32_t *__restrict__ packed, int n, int n_alloc, uint8_t *__restrict__ out)
+{
+    const int row = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = lane_id();
+    if (row >= n_alloc) return;
+    uint32_t v = 0;
+    if (row < n) {
+        const uint32_t w = packed[(size_t)row * 8 + (lane >> 3)];
+        const uint32_t nib = (w >> (4 * (lane & 7))) & 15u;
+        v = 0xC0C0C0C0u ^ (((nib * 0x00204081u) & 0x01010101u) << 7);
+    }
+    *(uint32_t *)(out + (size_t)row * 256 + 4 * lane) = v;
+}
+
 /* raw local match of a database shard -> the 8-byte records ranks exchange (include/sendslam_orb.h ss_match_part) */
 static_assert(sizeof(match_partial) == sizeof(ss_match_part) && offsetof(match_partial, j1) == offsetof(ss_match_part, row),
               "the chunk partial IS the cross-shard record");
@@ -2489,6 +2505,44 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
         hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, (const match_partial *)partial, nq_arr, nq_fixed, n_chunks, th, rnum,
                            rden, out_stride, idx, d1, d2);
     }
+}
+
+void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out)
+{
+    const int n_alloc = (n + MM_TILE - 1) & ~(MM_TILE - 1);
+    if (n_alloc > 0) hipLaunchKernelGGL(k_expand_desc, dim3((n_alloc + 3) / 4), dim3(256), 0, s, (const uint32_t *)packed, n, n_alloc, (uint8_t *)out);
+}
+
+/* one query set against one (large) train set, both expanded: chunks of <= 8192 rows (the key's row field), the 16
+ * query blocks of a chunk adjacent in the grid (one XCD streams the chunk once) */
+int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len)
+{
+    const int n_qblocks = (n_query + 127) / 128;
+    int want = (2048 + n_qblocks - 1) / n_qblocks; /* >= 2048 blocks when the train set allows */
+    const int max_chunks = (n_train + 255) / 256;  /* >= 8 tiles per block */
+    if (want > max_chunks) want = max_chunks;
+    if (want < 1) want = 1;
+    int len = ((n_train + want - 1) / want + MM_TILE - 1) & ~(MM_TILE - 1);
+    if (len > (1 << MX_ROW_BITS)) len = 1 << MX_ROW_BITS;
+    if (len < MM_TILE) len = MM_TILE;
+    *chunk_len = len;
+    const int n = (n_train + len - 1) / len;
+    return n < 1 ? 1 : n;
+}
+
+void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uint8_t *train_x, int nt, int chunk_len, int n_chunks,
+                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2)
+{
+    dim3 grid(((nq + 127) / 128) * n_chunks);
+    hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
+                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, th, rnum, rden, nq, (match_partial *)partial,
+                       idx, d1, d2);
+    if (n_chunks >= 32)
+        hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
+                           idx, d1, d2);
+    else if (n_chunks > 1)
+        hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256, 1), dim3(256), 0, s, (const match_partial *)partial,
+                           (const int32_t *)nullptr, nq, n_chunks, th, rnum, rden, nq, idx, d1, d2);
 }
 
 void ssk_match(hipStream_t s, const void *query, const void *train, const int32_t *nq_arr, const int32_t *nt_arr,

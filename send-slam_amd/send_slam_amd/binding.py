@@ -26,7 +26,8 @@ EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy",
            "ss_set_calibration", "ss_extract", "ss_extract_batch_device", "ss_get_batch_view", "ss_fetch_frame", "ss_match",
            "ss_match_device", "ss_match_batch_device", "ss_track", "ss_track_reset", "ss_synchronize", "ss_get_stream",
            "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort",
-           "ss_match_pairs_device", "ss_track_features", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
+           "ss_match_pairs_device", "ss_expand_descriptors_device", "ss_match_expanded_device",
+           "ss_match_partial_expanded_device", "ss_track_features", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
            "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
            "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight"]
 
@@ -151,6 +152,9 @@ def load():
     lib.ss_debug_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.ss_match_pairs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ss_expand_descriptors_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.ss_match_expanded_device.argtypes = lib.ss_match.argtypes
+    lib.ss_match_partial_expanded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     lib.ss_track_features.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Pose)]
     lib.ss_match_partial_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     lib.ss_match_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -319,6 +323,24 @@ class OrbContext:
         self._check(self._lib.ss_match_pairs_device(self._h, C.c_void_p(d_q), C.c_void_p(d_nq), C.c_void_p(d_t), C.c_void_p(d_nt),
                                                     n_frames, rows_per_frame, th, ratio_num, ratio_den, C.c_void_p(d_idx),
                                                     C.c_void_p(d_d1), C.c_void_p(d_d2)))
+
+    @staticmethod
+    def expanded_bytes(n: int) -> int:
+        """bytes of n descriptors in the matrix-core matcher's operand format (256 B per row, rows rounded up to 32)"""
+        return ((n + 31) & ~31) * 256
+
+    def expand_descriptors_device(self, d_packed: int, n: int, d_expanded: int):
+        self._check(self._lib.ss_expand_descriptors_device(self._h, C.c_void_p(d_packed), n, C.c_void_p(d_expanded)))
+
+    def match_expanded_device(self, d_qx: int, nq: int, d_tx: int, nt: int, d_idx: int, d_d1: int, d_d2: int, th: int = 50,
+                              ratio_num: int = 9, ratio_den: int = 10, exclude_self: bool = False):
+        self._check(self._lib.ss_match_expanded_device(self._h, C.c_void_p(d_qx), nq, C.c_void_p(d_tx), nt, th, ratio_num,
+                                                       ratio_den, int(exclude_self), C.c_void_p(d_idx), C.c_void_p(d_d1),
+                                                       C.c_void_p(d_d2)))
+
+    def match_partial_expanded_device(self, d_qx: int, nq: int, d_tx: int, nt: int, row_offset: int, d_part: int):
+        self._check(self._lib.ss_match_partial_expanded_device(self._h, C.c_void_p(d_qx), nq, C.c_void_p(d_tx), nt,
+                                                               int(row_offset), C.c_void_p(d_part)))
 
     def match_partial_device(self, d_q: int, nq: int, d_t: int, nt: int, row_offset: int, d_part: int):
         """Raw local match of a database shard -> nq 8-byte ss_match_part records (global rows) at d_part."""

@@ -118,8 +118,19 @@ def hip_local_match(ctx) -> LocalMatch:
     return run
 
 
+def expand_database(ctx, db_slab: torch.Tensor) -> torch.Tensor:
+    """A rank's database slab (u8 [n, 32]) in the matrix-core matcher's operand format (u8 [n rounded up to 32, 256]),
+    prepared ONCE: the per-query match then expands nothing (ss_expand_descriptors_device)."""
+    n = db_slab.shape[0]
+    out = torch.empty((ctx.expanded_bytes(n) // 256, 256), dtype=torch.uint8, device=db_slab.device)
+    with on_ctx_stream(ctx, db_slab.device):
+        ctx.expand_descriptors_device(db_slab.data_ptr(), n, out.data_ptr())
+    ctx.synchronize()
+    return out
+
+
 def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, th: int = 50,
-                              ratio_num: int = 9, ratio_den: int = 10, src: int = 0, out=None):
+                              ratio_num: int = 9, ratio_den: int = 10, src: int = 0, out=None, db_expanded=None, n_db=None):
     """Config 5 on the GPUs, behind the C ABI: broadcast -> ss_match_partial_device -> all_gather of
     world x nq x 8 B -> ss_match_fold_device, all on the context's stream (no host synchronisation inside;
     the caller synchronises when it reads the result).  Returns device tensors (idx i32, d1 i16, d2 i16:
@@ -135,8 +146,15 @@ def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, s
             else:
                 dist.broadcast(query, src=src)
         part = torch.empty(nq, dtype=torch.int64, device=dev)  # nq x ss_match_part (8 B)
-        nt = db_slab.shape[0]
-        ctx.match_partial_device(query.data_ptr(), nq, db_slab.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+        if db_expanded is not None:
+            # the slab was expanded once (expand_database); the query is expanded per call (nq x 256 B)
+            nt = db_slab.shape[0] if n_db is None else n_db
+            qx = torch.empty((ctx.expanded_bytes(nq) // 256, 256), dtype=torch.uint8, device=dev)
+            ctx.expand_descriptors_device(query.data_ptr(), nq, qx.data_ptr())
+            ctx.match_partial_expanded_device(qx.data_ptr(), nq, db_expanded.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+        else:
+            nt = db_slab.shape[0]
+            ctx.match_partial_device(query.data_ptr(), nq, db_slab.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
         if world > 1:
             if dist.get_backend() == "gloo":
                 ctx.synchronize()

@@ -72,7 +72,9 @@ def run(rank, world, port, use_gpu, out_dir):
             for k, seed in enumerate((5, 6, 7)):
                 qk, dbk = make_db(seed, 4001, 150)
                 query = torch.from_numpy(qk if rank == 0 else np.zeros_like(qk)).to(dev)
-                idx, d1, d2 = multi.loop_closure_query_device(ctx, query, torch.from_numpy(dbk[b:e]).to(dev), b, th=256, ratio_num=10)
+                slab_t = torch.from_numpy(dbk[b:e]).to(dev)
+                kw = {"db_expanded": multi.expand_database(ctx, slab_t)} if k == 2 else {}  # the last one on the expanded slab
+                idx, d1, d2 = multi.loop_closure_query_device(ctx, query, slab_t, b, th=256, ratio_num=10, **kw)
                 ctx.synchronize()
                 np.savez(os.path.join(out_dir, f"lcd{k}_{rank}.npz"), idx=idx.cpu().numpy(), d1=d1.cpu().numpy().view(np.uint16),
                          d2=d2.cpu().numpy().view(np.uint16))

@@ -244,3 +244,44 @@ def test_partial_and_fold_equal_one_match(oracle, n_parts, nq, n_db):
             assert np.array_equal(d1.cpu().numpy().view(np.uint16), want[1]) and np.array_equal(d2.cpu().numpy().view(np.uint16), want[2])
         rec = parts.cpu().numpy().view(np.dtype([("d1", "<u2"), ("d2", "<u2"), ("row", "<i4")]))
         assert rec.shape == (n_parts, nq) and rec["row"][0, 0] == 3 and rec["row"][1, 0] == per + 5 and rec["d1"][1, 1] == 0
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 150001), (129, 8193), (5, 70000), (300, 31), (64, 0), (1, 1), (2000, 2000)])
+def test_expanded_operands_match_equals_oracle(oracle, nq, nt):
+    """ss_expand_descriptors_device + ss_match_expanded_device (the database expanded once to the matrix-core operand
+    format, nothing expanded per query) == the oracle's match on the packed descriptors: sizes on both sides of the
+    8192-row chunk and 32-row tile limits, ties planted across chunk boundaries, the self-match form."""
+    import torch
+    rng = np.random.default_rng(nq * 7 + nt)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, size=(nt, 32), dtype=np.uint8)
+    if nt > 20000:
+        t[8191] = q[0]; t[8192] = q[0]          # exact duplicate on both sides of a chunk boundary: lowest row wins, d2 = 0
+        t[nt - 1] = q[1]                         # best in the last, partial tile
+        t[16383] = q[2]; t[16383, 0] ^= 1; t[16384] = q[2]; t[16384, 5] ^= 3
+    dev = torch.device("cuda:0")
+    tq, tt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    idx = torch.empty(nq, dtype=torch.int32, device=dev)
+    d1 = torch.empty(nq, dtype=torch.int16, device=dev)
+    d2 = torch.empty(nq, dtype=torch.int16, device=dev)
+    with binding.OrbContext(0) as ctx:
+        qx = torch.empty(ctx.expanded_bytes(nq), dtype=torch.uint8, device=dev)
+        tx = torch.empty(max(ctx.expanded_bytes(nt), 256), dtype=torch.uint8, device=dev)
+        ctx.expand_descriptors_device(tq.data_ptr(), nq, qx.data_ptr())
+        ctx.expand_descriptors_device(tt.data_ptr() if nt else 0, nt, tx.data_ptr())
+        ctx.synchronize()
+        x = qx.cpu().numpy()[:nq * 256].reshape(nq, 256)
+        bits = np.unpackbits(q, axis=1, bitorder="little")
+        assert np.array_equal(x, np.where(bits == 1, 0x40, 0xC0).astype(np.uint8))
+        for kw in (dict(th=50, ratio_num=9), dict(th=-1, ratio_num=1)):
+            ctx.match_expanded_device(qx.data_ptr(), nq, tx.data_ptr(), nt, idx.data_ptr(), d1.data_ptr(), d2.data_ptr(), **kw)
+            ctx.synchronize()
+            want = oracle.match(q, t, **kw)
+            assert np.array_equal(idx.cpu().numpy(), want[0])
+            assert np.array_equal(d1.cpu().numpy().view(np.uint16), want[1]) and np.array_equal(d2.cpu().numpy().view(np.uint16), want[2])
+        if nq == nt:
+            ctx.match_expanded_device(qx.data_ptr(), nq, qx.data_ptr(), nq, idx.data_ptr(), d1.data_ptr(), d2.data_ptr(), th=256,
+                                      ratio_num=10, exclude_self=True)
+            ctx.synchronize()
+            want = oracle.match(q, q, th=256, ratio_num=10, exclude_self=True)
+            assert np.array_equal(idx.cpu().numpy(), want[0]) and np.array_equal(d1.cpu().numpy().view(np.uint16), want[1])
