@@ -44,7 +44,8 @@ for p in (ROOT, os.path.join(ROOT, "send-slam_amd")):
 
 import numpy as np  # noqa: E402
 
-INT8_MFMA_PEAK_OPS = 5.0e15  # dense int8 MFMA, 2 x the 2.5e15 dense bf16 peak (MI355X_MICROARCH.md)
+FP4_MFMA_PEAK_OPS = 10.0e15  # dense FP4 MFMA (MI355X_MICROARCH.md "Peak FP6/FP4 MFMA ~10 PF dense"; measured issue rate: profiles/r02_fp4_probe.txt)
+INT8_MFMA_PEAK_OPS = 5.0e15  # dense int8 MFMA: the packed-descriptor kernel k_match_mfma (SENDSLAM_LC_PACKED=1)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 CACHE_BYTES = 256 << 20  # Infinity Cache: the rotating device batches must exceed it
 
@@ -185,8 +186,8 @@ def bench_loop_closure(a):
     out = (torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, dtype=torch.int16, device=dev),
            torch.empty(nq, dtype=torch.int16, device=dev))
     steps = a.steps if a.steps else 20
-    # the keyframe database is static: its slab is expanded once to the matrix-core matcher's operand format (256 B per
-    # descriptor: 5.1 GB for the whole database, 640 MB per GPU at 8); SENDSLAM_LC_PACKED=1 keeps the packed rows and
+    # the keyframe database is static: its slab is expanded once to the matrix-core matcher's operand format (128 B per
+    # descriptor: 2.6 GB for the whole database, 320 MB per GPU at 8); SENDSLAM_LC_PACKED=1 keeps the packed rows and
     # the expanding kernel (k_match_mfma<2>) instead
     dbx = None if os.environ.get("SENDSLAM_LC_PACKED") == "1" else multi.expand_database(ctx, db)
     kw = {} if dbx is None else {"db_expanded": dbx, "n_db": e - b}
@@ -216,8 +217,9 @@ def bench_loop_closure(a):
         roof = None
         if mk and mk["mean_ms"] > 0:
             t = mk["mean_ms"] * 1e-3
+            peak = INT8_MFMA_PEAK_OPS if dbx is None else FP4_MFMA_PEAK_OPS
             roof = {"kernel": ("match (k_match_mfma<2>" if dbx is None else "match (k_match_mfma_x on the expanded slab") + " + merge, this rank's slab)", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
-                    "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
+                    "peak": peak / 1e12, "unit": "Top/s (int8 MFMA)" if dbx is None else "Top/s (FP4 MFMA, +-1 operands, exact)", "frac": round(pairs * 512 / t / peak, 4),
                     "kernel_ms": round(mk["mean_ms"], 4), "traffic": None}
         print(json.dumps({
             "metric": "loop-closure queries/sec (2000 descriptors vs 10k-keyframe database)", "value": round(steps / elapsed, 3),
@@ -226,7 +228,7 @@ def bench_loop_closure(a):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
                                    "raw local match -> 8-byte records, all_gather, fold kernel", "parallelism": f"db slabs x {world}",
-                       "database_format": "packed 32 B rows" if dbx is None else "expanded once to 256 B rows (matrix-core operand)"},
+                       "database_format": "packed 32 B rows" if dbx is None else "expanded once to 128 B rows of FP4 +-1 (matrix-core operand)"},
             "roofline": roof, "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
             "pairs_per_s": float(f"{nq * n_db * steps / elapsed:.4g}")}))
     ctx.close()
@@ -720,11 +722,10 @@ def main():
                     "note": "integer-VALU-bound kernel (DESIGN.md section 5): the HBM fraction is reported because the contract "
                             "asks for it, not because HBM limits it; see valu_roofline"}
 
-    # the Hamming-match kernel (k_match_mfma) against the two pipes it uses: the distance of a
-    # (query, train) pair is a 256-term i8 contraction on the matrix cores (512 int8 ops), the best / second-best
-    # selection stays on the VALU: per pair one v_lshl_add_u32 (key), one v_med3_u32, one v_min_u32, priced with the
-    # measured instruction costs (profiles/r01_valu_rates.json, profiles/tools/valu_rates.hip).  Peak int8 MFMA: 2 x
-    # the dense bf16 rate (MI355X_MICROARCH.md "Matrix cores": i8 = bf16 cycles at 2 x K) = 5.0e15 op/s.
+    # the Hamming-match kernel (k_match_mfma_x) against the two pipes it uses: the distance of a
+    # (query, train) pair is a 256-term contraction of FP4 +-1 values on the matrix cores (512 ops, exact in f32), the
+    # best / second-best selection stays on the VALU: per pair one v_med3_u32 and one v_min_u32 (the key IS the
+    # accumulator), priced with the measured instruction costs (profiles/r01_valu_rates.json).
     match_roofline = None
     mk = next((k for k in kernels if k["name"] == "match"), None)
     rpath = os.path.join(ROOT, "profiles", "r01_valu_rates.json")
@@ -733,15 +734,17 @@ def main():
         t = mk["isolated_mean_ms"] * 1e-3
         rates = json.load(open(rpath))
         c = rates["cycles_per_wave64_instruction_per_simd"]
-        sel = c["v_lshl_add_u32"] + c["v_med3_u32"] + c["v_min_u32"]
+        sel = c["v_med3_u32"] + c["v_min_u32"]
         simd_cycles_per_s = rates["cus"] * 4 * rates["clock_mhz"] * 1e6
         valu_floor_ms = pairs / 64 * sel / simd_cycles_per_s * 1e3
-        mfma_floor_ms = pairs * 512 / INT8_MFMA_PEAK_OPS * 1e3
-        match_roofline = {"kernel": "match", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
-                          "peak": INT8_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (int8)", "frac": round(pairs * 512 / t / INT8_MFMA_PEAK_OPS, 4),
+        mfma_floor_ms = pairs * 512 / FP4_MFMA_PEAK_OPS * 1e3
+        match_roofline = {"kernel": "match (k_match_mfma_x + merge)", "bound": "mfma", "achieved": float(f"{pairs * 512 / t / 1e12:.4g}"),
+                          "peak": FP4_MFMA_PEAK_OPS / 1e12, "unit": "Top/s (FP4 MFMA, +-1 operands, exact)", "frac": round(pairs * 512 / t / FP4_MFMA_PEAK_OPS, 4),
                           "kernel_ms": mk["isolated_mean_ms"], "mfma_floor_ms": round(mfma_floor_ms, 4),
                           "valu_select_cycles_per_64_pairs": round(sel, 1), "valu_select_floor_ms": round(valu_floor_ms, 4),
-                          "pairs_per_s": float(f"{pairs / t:.4g}")}
+                          "pairs_per_s": float(f"{pairs / t:.4g}"),
+                          "note": "the instruction sustains 7.6e15 op/s on this chip under load (profiles/r02_fp4_probe.txt: 17.6 ns per 32x32x64 "
+                                  "instruction and SIMD), and 5 are issued per 4 needed (the fifth advances the row index)"}
 
     # the dominant kernel against the resource that bounds it: VALU issue.  Instructions per FRAME from the committed
     # PMC pass (profiles/per_frame_counters.json: SQ_INSTS_VALU of full-batch launches / frames), duration live; peak =

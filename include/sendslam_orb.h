@@ -218,13 +218,14 @@ int ss_track(ss_ctx *ctx, int camera_id, const uint8_t *pix, int width, int heig
 /* back to NO_IMAGES_YET (System::Reset / the "terminate" message :462-469) */
 int ss_track_reset(ss_ctx *ctx);
 
-/* The matrix-core matcher reads descriptors as rows of 256 bytes (one byte per bit, +64 / -64).  The frames of a batch
- * get that form from the extraction itself; a database that is matched against again and again (loop closure,
- * relocalisation: SURVEY.md section 8(e) config 5) is expanded ONCE: n descriptors of 32 B at d_packed -> rows of 256 B
+/* The matrix-core matcher reads descriptors as rows of 256 FP4 values (one per bit, +1 / -1: 128 bytes).  The frames of a
+ * batch get that form from the extraction itself; a database that is matched against again and again (loop closure,
+ * relocalisation: SURVEY.md section 8(e) config 5) is expanded ONCE: n descriptors of 32 B at d_packed -> rows of 128 B
  * at d_expanded, which must hold n rounded up to a multiple of 32 rows (SS_EXPANDED_BYTES(n)).  ss_match_expanded_device
  * is ss_match_device on two expanded operands (same rule, same outputs, any sizes); ss_match_partial_expanded_device is
  * ss_match_partial_device on them. */
-#define SS_EXPANDED_BYTES(n) ((((int64_t)(n) + 31) & ~(int64_t)31) * 256)
+#define SS_EXPANDED_ROW_BYTES 128
+#define SS_EXPANDED_BYTES(n) ((((int64_t)(n) + 31) & ~(int64_t)31) * SS_EXPANDED_ROW_BYTES)
 int ss_expand_descriptors_device(ss_ctx *ctx, const void *d_packed, int n, void *d_expanded);
 int ss_match_expanded_device(ss_ctx *ctx, const void *d_query_x, int n_query, const void *d_train_x, int n_train, int th,
                              int ratio_num, int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2);

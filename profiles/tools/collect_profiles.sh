@@ -18,4 +18,4 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_stream_f -- $B --profile-extra match_stream > /dev/null 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_stream_w -- $B --profile-extra match_stream > /dev/null 2>&1 && echo "pmc stream ok" &&
 python3 $R/profiles/tools/pcie_probe.py > $O/${TAG}_pcie.json 2> /dev/null &&
-$R/profiles/tools/mfma_probe > $O/${TAG}_mfma_probe.txt && echo "probes ok"
+$R/profiles/tools/mfma_probe > $O/${TAG}_mfma_probe.txt && $R/profiles/tools/fp4_probe > $O/${TAG}_fp4_probe.txt && echo "probes ok"

@@ -96,7 +96,7 @@ for src, dst in ((f"{tag}_prof4", f"{tag}_bench_kernel_stats.csv"), (f"{tag}_pro
     if f:
         shutil.copy(f, os.path.join(here, dst))
 for src, dst in ((f"{tag}_bench_final.json", f"{tag}_bench.json"), (f"{tag}_pcie.json", f"{tag}_pcie.json"),
-                 (f"{tag}_mfma_probe.txt", f"{tag}_mfma_probe.txt"), (f"{tag}_loop_closure.json", f"{tag}_loop_closure.json")):
+                 (f"{tag}_mfma_probe.txt", f"{tag}_mfma_probe.txt"), (f"{tag}_fp4_probe.txt", f"{tag}_fp4_probe.txt"), (f"{tag}_loop_closure.json", f"{tag}_loop_closure.json")):
     if os.path.exists(os.path.join(out_dir, src)):
         shutil.copy(os.path.join(out_dir, src), os.path.join(here, dst))
 tot = sum(v.get("SQ_INSTS_VALU", 0) for v in sq.values())

@@ -75,7 +75,7 @@ struct ss_ctx {
     int32_t *n_kp = nullptr, *level_counts = nullptr, *frame_error = nullptr;
     ss_keypoint *kps = nullptr;
     uint8_t *desc = nullptr;
-    uint8_t *desc_x = nullptr; /* the descriptors as 256 bytes of +1 / -1 per row: operand of the batch matcher */
+    uint8_t *desc_x = nullptr; /* the descriptors as 256 FP4 values (+1 / -1) per row, 128 B: operand of the batch matcher */
 
     uint8_t *d_in = nullptr;
     size_t d_in_bytes = 0;
@@ -260,8 +260,8 @@ int ensure_geometry(ss_ctx *c, int w, int h)
     HIP_TRY(c, hipMemset(c->desc, 0, B * g.kcap * SS_DESC_BYTES));
     if (!c->no_desc_x && g.kcap >= SSK_MATCH_MFMA_MIN_QUERIES) {
         /* zeroed once: a row that was never written contributes 0 to every dot product (and is masked out anyway) */
-        HIP_TRY(c, hipMalloc((void **)&c->desc_x, B * g.kcap * 256));
-        HIP_TRY(c, hipMemset(c->desc_x, 0, B * g.kcap * 256));
+        HIP_TRY(c, hipMalloc((void **)&c->desc_x, B * g.kcap * SSK_X_ROW));
+        HIP_TRY(c, hipMemset(c->desc_x, 0, B * g.kcap * SSK_X_ROW));
     }
     c->have_geom = true;
     c->last_n_frames = 0;
@@ -635,13 +635,14 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
     int chunk_len = 4;
     int n_chunks = ssk_match_chunks(kcap, kcap, n, &chunk_len);
     if (c->desc_x) {
-        if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) { /* experiment knob */
-            const int want = atoi(e);
-            if (want >= 1) {
-                chunk_len = ((kcap + want - 1) / want + 31) & ~31;
-                n_chunks = (kcap + chunk_len - 1) / chunk_len;
-            }
-        }
+        /* k_match_mfma_x: ~3200 blocks of 128 queries x one train chunk of >= 8 tiles (measured at 64 x 2112 rows: 1 chunk
+         * 0.062 ms, 2 -> 0.059, 3 -> 0.057, 4 -> 0.058); SENDSLAM_MX_CHUNKS overrides (experiments) */
+        const int q_groups = ((kcap + 127) / 128) * n;
+        int want = (3200 + q_groups / 2) / q_groups;
+        if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) want = atoi(e);
+        want = std::max(1, std::min(want, (kcap + 255) / 256));
+        chunk_len = ((kcap + want - 1) / want + 31) & ~31;
+        n_chunks = (kcap + chunk_len - 1) / chunk_len;
     }
     if (n_chunks > 1) {
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n * n_chunks * kcap * SSK_MATCH_PARTIAL_BYTES);
@@ -651,7 +652,7 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
         const int64_t nf = c->hg.n_features;
         stage_timer t(c, "match", (int64_t)n * (nf * 32 * 2 + nf * 8));
         if (c->desc_x)
-            ssk_match_x(c->stream, c->desc_x, c->desc_x, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 256, (int64_t)kcap * 256,
+            ssk_match_x(c->stream, c->desc_x, c->desc_x, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * SSK_X_ROW, (int64_t)kcap * SSK_X_ROW,
                         mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
                         c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
         else
@@ -771,7 +772,7 @@ int ss_expand_descriptors_device(ss_ctx *c, const void *d_packed, int n, void *d
     if (n < 0) return fail(c, SS_ERR_INVALID_ARG, "bad descriptor count");
     if (n == 0) return SS_OK;
     if (!d_packed || !d_expanded) return fail(c, SS_ERR_INVALID_ARG, "NULL descriptor buffer");
-    stage_timer t(c, "expand", (int64_t)n * (32 + 256));
+    stage_timer t(c, "expand", (int64_t)n * (32 + SSK_X_ROW));
     ssk_expand_desc(c->stream, d_packed, n, d_expanded);
     HIP_TRY(c, hipGetLastError());
     return SS_OK;
@@ -792,7 +793,7 @@ int ss_match_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, cons
         if (rc != SS_OK) return rc;
     }
     {
-        stage_timer t(c, "match", (int64_t)n_query * 256 + (int64_t)n_train * 256 + (int64_t)n_query * 8);
+        stage_timer t(c, "match", (int64_t)n_query * SSK_X_ROW + (int64_t)n_train * SSK_X_ROW + (int64_t)n_query * 8);
         ssk_match_x_single(c->stream, (const uint8_t *)d_query_x, n_query, (const uint8_t *)(d_train_x ? d_train_x : d_query_x), n_train,
                            chunk_len, n_chunks, exclude_self, th, ratio_num, ratio_den, c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1,
                            (uint16_t *)d_d2);

@@ -53,13 +53,14 @@ void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, con
 /* cross-shard fold: parts [n_parts][nq] in ascending row order -> final outputs (k_match_merge's rule) */
 void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int th, int rnum, int rden, int32_t *idx,
                     uint16_t *d1, uint16_t *d2);
-/* the matrix-core matcher on descriptors already expanded to one +1 / -1 byte per bit (desc_x, 256 B per row, written by
- * ssk_orient_describe): batches of frames; frame strides in BYTES; >= 128 rows per frame, multiples of 32 allocated */
+/* the matrix-core matcher on descriptors already expanded to one FP4 value (+1 / -1) per bit (desc_x, SSK_X_ROW bytes per
+ * row, written by ssk_orient_describe): batches of frames; frame strides in BYTES; multiples of 32 rows allocated */
+#define SSK_X_ROW 128
 void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
                  int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
                  int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
                  uint16_t *d1, uint16_t *d2, int n_frames);
-/* packed 32-B descriptors -> expanded 256-B rows; `out` holds n rounded up to 32 rows */
+/* packed 32-B descriptors -> expanded SSK_X_ROW-byte rows; `out` holds n rounded up to 32 rows */
 void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out);
 /* one expanded query set against one expanded train set (any size): chunk plan + launch (+ merge of the chunk partials) */
 int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len);

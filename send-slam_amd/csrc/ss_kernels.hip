@@ -1418,6 +1418,19 @@ __global__ __launch_bounds__(64) void k_slots(const ss_geom *__restrict__ g, con
 /* ------------------------------------------------------------------------------------ */
 static_assert(offsetof(ss_geom, ic_mask) % 16 == 0 && offsetof(ss_geom, pat4) % 16 == 0, "ic_mask and pat4 are loaded as dwordx4");
 
+/* Operand format of the matrix-core matcher (k_match_mfma_x): a descriptor is 256 FP4 (e2m1) values, bit set -> +1.0
+ * (nibble 0x2), bit clear -> -1.0 (nibble 0xA), bit b in nibble b of the 128-byte row.  Four bits -> four nibbles:
+ * nibble -> four 0 / 1 bytes by one multiplication, bytes squeezed to nibbles by two shift-or-and steps, then
+ * 0xA ^ (bit << 3). */
+#define SS_X_ROW 128
+__device__ __forceinline__ uint32_t fp4_of_4bits(uint32_t nib)
+{
+    uint32_t p = (nib * 0x00204081u) & 0x01010101u;
+    p = (p | (p >> 4)) & 0x00110011u;
+    p = (p | (p >> 8)) & 0x00001111u;
+    return 0xAAAAu ^ (p << 3);
+}
+
 /* STEER_FMA: how the rotated tap coordinates cvRound(x*b + y*a), cvRound(x*a - y*b) are evaluated.  false = two
  * products and one sum, each rounded (the C expression as written); true = what GCC's FMA contraction makes of it
  * when upstream is built -O3 -march=native (CMakeLists.txt:10-13): the FIRST product fused into the sum,
@@ -1608,14 +1621,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
 #pragma unroll
         for (int q = 0; q < 4; q++) words[q] = __ballot(t0[k][q] < t1[k][q]);
         if (desc_x) {
-            /* the same 256 bits as bytes: bit b of the descriptor -> byte b = +64 (set) / -64 (clear).  k_match_mfma_x reads
-             * these rows as i8 MFMA operands (the dot product of a row with a sign-flipped row is 8192 * hamming - 2^20)
-             * without expanding anything in its loop.  Lane L writes bytes 4 L .. 4 L + 3 = bits 4 L .. 4 L + 3: one
-             * coalesced 256-byte store per wave.  Nibble -> four 0 / 1 bytes by one multiplication, then 0 -> 0xC0, 1 -> 0x40. */
+            /* the same 256 bits as the matcher's operand row (fp4_of_4bits): lane L writes nibbles 4 L .. 4 L + 3 = bits
+             * 4 L .. 4 L + 3, two bytes: one coalesced 128-byte store per wave */
             const uint64_t wsel = lane < 16 ? words[0] : lane < 32 ? words[1] : lane < 48 ? words[2] : words[3];
             const uint32_t nib = (uint32_t)(wsel >> (4 * (lane & 15))) & 15u;
-            const uint32_t b01 = (nib * 0x00204081u) & 0x01010101u;
-            *(uint32_t *)(desc_x + ((size_t)frame * kcap + slot[k]) * 256 + 4 * lane) = 0xC0C0C0C0u ^ (b01 << 7);
+            *(uint16_t *)(desc_x + ((size_t)frame * kcap + slot[k]) * SS_X_ROW + 2 * lane) = (uint16_t)fp4_of_4bits(nib);
         }
         if (lane == 0) {
             const ss_level &L = g->lv[level[k]];
@@ -2005,30 +2015,37 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* K7 on the matrix cores, operands already expanded (k_orient_describe's desc_x: one byte per descriptor bit, +64 / -64). */
-/* Same contraction, same rule, same grid contract and outputs as k_match_mfma, but the loop neither expands nor forms     */
-/* keys:                                                                                                                    */
-/* * a 32-row train tile is 8 KB of consecutive bytes that the block copies global -> LDS by LDS-DMA                        */
-/*   (global_load_lds_dwordx4: no VGPR, no VALU, no lookup table) one phase ahead of the MFMAs that read it; the query       */
-/*   fragments are eight 16-byte global loads per lane, sign-flipped once (x ^ 0x80: +64 <-> -64).  LDS image: rows at a     */
-/*   272-byte pitch (ds_read_b128 of 32 rows x 16 bytes is conflict-free there); a DMA instruction writes 64 consecutive     */
-/*   16-byte units, so each lane's SOURCE address places the padding (unit u -> row u / 17, piece u % 17; piece 16 = pad).   */
-/* * products are +-4096, so the 256-term dot product is 8192 * hamming - 2^20, and the accumulator INPUT of a tile is      */
-/*   2^20 + the row's index in the chunk: the MFMA result IS the key 8192 * hamming + row (smallest key = best distance at   */
-/*   the lowest row, second smallest carries the second-best distance).  The row-index vector advances by 32 per tile with   */
-/*   one extra MFMA (A0 = 4, B0 = 8 in k-slot 0: +32 everywhere) instead of 16 VALU additions per lane: the matrix pipe has   */
-/*   the room, the VALU does not.  Selection: v_med3_u32 + v_min_u32 per pair, nothing else.                                  */
-/* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their accumulator input, in the      */
-/*   few tiles that contain such rows (wave-uniform test).                                                                    */
-/* Chunks are <= 8192 rows (13-bit row field).                                                                                */
+/* K7 on the matrix cores, operands already expanded (k_orient_describe's desc_x / k_expand_desc: one FP4 value per           */
+/* descriptor bit, +1 / -1, 128 bytes per row).  Same contraction, same rule, same grid contract and outputs as                */
+/* k_match_mfma, but the loop neither expands nor forms keys, and the contraction runs at the FP4 rate:                         */
+/* * v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands takes the time of the i8 32x32x32 instruction for twice the K           */
+/*   (profiles/tools/fp4_probe.hip: 17.6 ns against 18.1 ns per instruction and SIMD): 4 instructions per 32-row tile           */
+/*   instead of 8.  The E8M0 block scale 2^12 on the train operand makes every product +-4096, so the 256-term dot product       */
+/*   of a row with a sign-flipped row is 8192 * hamming - 2^20, exact in f32 (|values| < 2^22).                                  */
+/* * a 32-row train tile is 4 KB of consecutive bytes that the block copies global -> LDS by LDS-DMA                            */
+/*   (global_load_lds_dwordx4: no VGPR, no VALU, no lookup table) MX_NBUF - 1 phases ahead of the MFMAs that read it; the        */
+/*   query fragments are four 16-byte global loads per lane, sign-flipped once (x ^ 0x88..: +1 <-> -1).  LDS image: rows at a    */
+/*   144-byte pitch (ds_read_b128 of 32 rows x 16 bytes is conflict-free there); a DMA instruction writes 64 consecutive         */
+/*   16-byte units, so each lane's SOURCE address places the padding (unit u -> row u / 9, piece u % 9; piece 8 = pad).          */
+/* * the accumulator INPUT of a tile is 2^20 + the row's index in the chunk: the MFMA result IS the key 8192 * hamming + row     */
+/*   as a non-negative float, whose bit pattern orders like the value (smallest key = best distance at the lowest row, second    */
+/*   smallest carries the second-best distance).  The row-index vector advances by 32 per tile with one extra MFMA               */
+/*   (4.0 x 4.0 x 2^1 in k-slot 0: +32 everywhere) instead of 16 VALU additions per lane: the matrix pipe has the room, the       */
+/*   VALU does not.  Selection: v_med3_u32 + v_min_u32 per pair, nothing else.                                                    */
+/* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their accumulator input, in the          */
+/*   few tiles that contain such rows (wave-uniform test).                                                                        */
+/* Chunks are <= 8192 rows (13-bit row field).                                                                                    */
 /* ------------------------------------------------------------------------------------ */
-#define MX_PITCH 272
-#define MX_UNITS (MM_TILE * (MX_PITCH / 16))     /* 544 16-byte units per tile image */
-#define MX_DMAS ((MX_UNITS + 63) / 64)           /* 9 DMA instructions per tile */
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+#define MX_PITCH (SS_X_ROW + 16)
+#define MX_UNITS (MM_TILE * (MX_PITCH / 16))     /* 288 16-byte units per tile image */
+#define MX_DMAS ((MX_UNITS + 63) / 64)           /* 5 DMA instructions per tile (the last one half used) */
 #define MX_BUF (MX_DMAS * 1024)
 #define MX_ROW_BITS 13
-#define MX_NONE (1 << 28)
-
+#define MX_NONE_F 268435456.0f /* 2^28 */
+#define MX_FMT_FP4 4
+#define MX_SCALE_ONE 127       /* E8M0: 2^(x - 127) */
 #ifndef MX_NBUF
 #define MX_NBUF 3 /* LDS ring: the DMA of a tile is issued MX_NBUF - 1 phases before the MFMAs that read it */
 #endif
@@ -2036,12 +2053,12 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
 #define MX_WAVES_PER_SIMD 5
 #endif
 
-__device__ __forceinline__ void mx_select(const v16i &acc, uint32_t (&k1)[2], uint32_t (&k2)[2])
+__device__ __forceinline__ void mx_select(const v16f &acc, uint32_t (&k1)[2], uint32_t (&k2)[2])
 {
     /* two independent (best, second) chains per lane; they merge once, at the end */
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const uint32_t key = (uint32_t)acc[r];
+        const uint32_t key = __float_as_uint(acc[r]);
         const int c = r & 1;
         k2[c] = min(max(k1[c], k2[c]), max(min(k1[c], k2[c]), key));
         k1[c] = min(k1[c], key);
@@ -2064,8 +2081,8 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
 {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[MX_NBUF][MX_BUF];
     /* 1-D grid, XCD-aware: every XCD gets a contiguous run of (frame, chunk, query block) triples, so the blocks that
-     * stream the same train rows share one L2 (dealt round-robin, the blocks of a frame would pull its 540 KB
-     * through all eight L2s) */
+     * stream the same train rows share one L2 (dealt round-robin, the blocks of a frame would pull its rows through all
+     * eight L2s) */
     const int n_qblocks = (out_stride + 127) / 128;
     const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int qblock = logical % n_qblocks, chunk = (logical / n_qblocks) % n_chunks, frame = logical / (n_qblocks * n_chunks);
@@ -2074,7 +2091,7 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
     const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
     const int nt = nt_arr ? nt_arr[tframe] : nt_fixed;
     const bool excl = exclude_self_mode == 1 || (exclude_self_mode == 2 && tframe == frame);
-    const uint8_t *qf = query_x + (size_t)frame * q_frame_stride; /* strides in bytes: rows of 256 */
+    const uint8_t *qf = query_x + (size_t)frame * q_frame_stride; /* strides in bytes: rows of SS_X_ROW */
     const uint8_t *tf = train_x + (size_t)tframe * t_frame_stride;
     const int lane = lane_id(), col = lane & 31, half = lane >> 5;
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -2083,13 +2100,13 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
     const int n_tiles = qblock * 128 < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
 
     /* source offsets of this lane's pieces inside a tile (the same for every tile): DMA m of the tile covers units
-     * 64 m .. 64 m + 63; wave w issues m = w, w + 4 (and w + 8 for wave 0) */
-    uint32_t src_off[3];
+     * 64 m .. 64 m + 63; wave w issues m = w (and m = 4 for wave 0) */
+    uint32_t src_off[2];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 2; k++) {
         const int u = imin(64 * (wave + 4 * k) + lane, MX_UNITS - 1);
-        const int r = u / (MX_PITCH / 16), j = imin(u - r * (MX_PITCH / 16), 15);
-        src_off[k] = (uint32_t)(r * 256 + j * 16);
+        const int r = u / (MX_PITCH / 16), j = imin(u - r * (MX_PITCH / 16), SS_X_ROW / 16 - 1);
+        src_off[k] = (uint32_t)(r * SS_X_ROW + j * 16);
     }
     /* every wave issues its DMAs for EVERY tile slot of the ring, also past the last tile (a harmless re-read of the
      * last tile): the count of vector-memory operations in flight is then the same in every phase, which is what the
@@ -2103,35 +2120,40 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
 #else
         const int t = imin(tile, imax(n_tiles - 1, 0));
 #endif
-        const uint8_t *src = tf + (size_t)(c0 + t * MM_TILE) * 256;
+        const uint8_t *src = tf + (size_t)(c0 + t * MM_TILE) * SS_X_ROW;
         uint8_t *dst = tiles[tile % MX_NBUF];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < 2; k++) {
             const int m = wave + 4 * k;
             if (m < MX_DMAS)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + src_off[k]),
                                                  (__attribute__((address_space(3))) void *)(dst + m * 1024), 16, 0, 0);
         }
     };
-    /* B fragments: k-step s, lane half h <-> bytes 32 s + 16 h .. + 15 of the query row, sign flipped */
-    v4i bq[8];
+    /* B fragments: k-step s, lane half h <-> bytes 32 s + 16 h .. + 15 of the query row (bits 64 s + 32 h .. + 31), sign flipped */
+    v4i bq4[4];
     {
         const int qi = qbase + col;
-        const uint8_t *qrow = qf + (size_t)(qi < nq ? qi : 0) * 256 + 16 * half;
+        const uint8_t *qrow = qf + (size_t)(qi < nq ? qi : 0) * SS_X_ROW + 16 * half;
 #pragma unroll
-        for (int sstep = 0; sstep < 8; sstep++) bq[sstep] = *(const v4i *)(qrow + 32 * sstep);
+        for (int sstep = 0; sstep < 4; sstep++) bq4[sstep] = *(const v4i *)(qrow + 32 * sstep);
     }
     if (n_tiles > 0) {
 #pragma unroll
         for (int t = 0; t < MX_NBUF - 1; t++) dma_tile(t);
     }
+    v8i bq[4];
 #pragma unroll
-    for (int sstep = 0; sstep < 8; sstep++) bq[sstep] = bq[sstep] ^ (int)0x80808080;
-    /* +32 everywhere: A0[m][0] = 4, B0[0][n] = 8, every other element 0 (k-slot 0 lives in byte 0 of lanes 0..31) */
-    const v4i a_step = v4i{half == 0 ? 4 : 0, 0, 0, 0}, b_step = v4i{half == 0 ? 8 : 0, 0, 0, 0};
-    v16i crow; /* accumulator input of the next tile: 2^20 + row index in the chunk */
+    for (int sstep = 0; sstep < 4; sstep++) {
+        const v4i f = bq4[sstep] ^ (int)0x88888888;
+        bq[sstep] = v8i{f[0], f[1], f[2], f[3], 0, 0, 0, 0};
+    }
+    /* +32 everywhere: A0[m][0] = 4.0, B0[0][n] = 4.0 (FP4 0x6), block scale 2^1, every other element 0 (k-slot 0 lives in
+     * nibble 0 of lanes 0..31) */
+    const v8i ab_step = v8i{half == 0 ? 6 : 0, 0, 0, 0, 0, 0, 0, 0};
+    v16f crow; /* accumulator input of the next tile: 2^20 + row index in the chunk */
 #pragma unroll
-    for (int r = 0; r < 16; r++) crow[r] = (1 << 20) + 4 * half + (r & 3) + 8 * (r >> 2);
+    for (int r = 0; r < 16; r++) crow[r] = (float)((1 << 20) + 4 * half + (r & 3) + 8 * (r >> 2));
     const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
     const int q_lo = qbase, q_hi = qbase + 32;
     uint32_t k1[2], k2[2];
@@ -2139,15 +2161,15 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
     for (int c = 0; c < 2; c++) k1[c] = k2[c] = 0xFFFFFFFFu;
     /* Phase i: { wait: this wave's DMAs of tile i have landed (those of the MX_NBUF - 2 younger tiles may still fly) |
      * barrier: so have everybody's, and everybody has finished reading tile i - 1 | refill tile i - 1's buffer with tile
-     * i + MX_NBUF - 1 | 8 + 1 MFMAs on tile i | selection }.  An LDS-DMA is a pending LDS write that only the issuing
+     * i + MX_NBUF - 1 | 4 + 1 MFMAs on tile i | selection }.  An LDS-DMA is a pending LDS write that only the issuing
      * wave's vmcnt tracks; hipcc does not always count it when it places the waits of __syncthreads() (one loop barrier
      * came out with lgkmcnt(0) only), hence the explicit counted waits and the raw barrier. */
     for (int i = 0; i < n_tiles; i++) {
 #if defined(MX_EXP) && MX_EXP == 1
         mx_wait_vm<0>();
 #else
-        if (wave == 0) mx_wait_vm<3 * (MX_NBUF - 2)>();
-        else mx_wait_vm<2 * (MX_NBUF - 2)>();
+        if (wave == 0) mx_wait_vm<2 * (MX_NBUF - 2)>();
+        else mx_wait_vm<1 * (MX_NBUF - 2)>();
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -2157,39 +2179,44 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         const int j0 = c0 + i * MM_TILE;
         const uint8_t *arow = &tiles[i % MX_NBUF][col * MX_PITCH + 16 * half];
         const bool masked = j0 + MM_TILE > c1 || (excl && j0 < q_hi && j0 + MM_TILE > q_lo);
-        v16i acc;
-        const v4i a0 = *(const v4i *)arow;
+        v16f acc;
+        v4i a4 = *(const v4i *)arow;
+        v8i a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
         if (masked) {
             const int rows_valid = c1 - j0, skip = excl ? qbase + col - j0 : -1;
-            v16i ci;
+            v16f ci;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = 4 * half + (r & 3) + 8 * (r >> 2);
-                ci[r] = crow[r] + ((row >= rows_valid || row == skip) ? MX_NONE : 0);
+                ci[r] = crow[r] + ((row >= rows_valid || row == skip) ? MX_NONE_F : 0.0f);
             }
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], ci, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0], ci, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
         } else {
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, bq[0], crow, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0], crow, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
         }
 #pragma unroll
-        for (int sstep = 1; sstep < 8; sstep++) {
-            const v4i a = *(const v4i *)(arow + 32 * sstep);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[sstep], acc, 0, 0, 0);
+        for (int sstep = 1; sstep < 4; sstep++) {
+            a4 = *(const v4i *)(arow + 32 * sstep);
+            a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[sstep], acc, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
         }
-        crow = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_step, b_step, crow, 0, 0, 0);
+        crow = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ab_step, ab_step, crow, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 1, 0, MX_SCALE_ONE);
         mx_select(acc, k1, k2);
     }
     mx_wait_vm<0>(); /* nothing of this block may still be writing LDS when the block retires */
     /* fold the two chains of a lane, then lanes l and l + 32 (same query, different train rows) */
     uint32_t f1 = min(k1[0], k1[1]), f2 = min(max(k1[0], k1[1]), min(k2[0], k2[1]));
     const uint32_t o1 = (uint32_t)__shfl_xor((int)f1, 32, 64), o2 = (uint32_t)__shfl_xor((int)f2, 32, 64);
-    const uint32_t m1 = min(f1, o1), m2 = min(max(f1, o1), min(f2, o2));
+    const uint32_t b1 = min(f1, o1), b2 = min(max(f1, o1), min(f2, o2));
     const int qi = qbase + col;
     if (half != 0 || qi >= out_stride) return;
     const bool qvalid = qi < nq;
-    const int d1 = m1 >= (uint32_t)MX_NONE ? 0xFFFF : (int)(m1 >> MX_ROW_BITS); /* only excluded rows were seen: none */
-    const int d2 = m2 >= (uint32_t)MX_NONE ? 0xFFFF : (int)(m2 >> MX_ROW_BITS);
-    const int j1 = d1 == 0xFFFF ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1));
+    /* keys are bit patterns of non-negative floats 8192 * hamming + row (< 2^22), or >= 2^28 / all ones for "none" */
+    const bool none1 = b1 >= __float_as_uint(MX_NONE_F), none2 = b2 >= __float_as_uint(MX_NONE_F);
+    const uint32_t m1 = none1 ? 0u : (uint32_t)__uint_as_float(b1), m2 = none2 ? 0u : (uint32_t)__uint_as_float(b2);
+    const int d1 = none1 ? 0xFFFF : (int)(m1 >> MX_ROW_BITS); /* only excluded rows were seen: none */
+    const int d2 = none2 ? 0xFFFF : (int)(m2 >> MX_ROW_BITS);
+    const int j1 = none1 ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1));
     if (n_chunks > 1) {
         match_partial mp;
         mp.d1 = (uint16_t)d1;
@@ -2227,9 +2254,9 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
     d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
 }
 
-/* packed descriptors (32 B) -> the matrix-core matcher's operand rows (256 B: bit b -> byte b = +64 / -64), the same
- * format k_orient_describe writes for the frames of a batch.  One wave per row, one coalesced 256-byte store; rows
- * n .. n_alloc - 1 (n_alloc = n rounded up to the 32-row tile) are zero-filled: they contribute 0 and are masked anyway. */
+/* packed descriptors (32 B) -> the matrix-core matcher's operand rows (SS_X_ROW bytes, fp4_of_4bits), the same format
+ * k_orient_describe writes for the frames of a batch.  One wave per row, one coalesced 128-byte store; rows n .. n_alloc - 1
+ * (n_alloc = n rounded up to the 32-row tile) are zero-filled (FP4 zeros: they contribute 0 and are masked anyway). */
 __global__ __launch_bounds__(256) void k_expand_desc(const uint32_t *__restrict__ packed, int n, int n_alloc, uint8_t *__restrict__ out)
 {
     const int row = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = lane_id();
@@ -2237,10 +2264,9 @@ __global__ __launch_bounds__(256) void k_expand_desc(const uint32_t *__restrict_
     uint32_t v = 0;
     if (row < n) {
         const uint32_t w = packed[(size_t)row * 8 + (lane >> 3)];
-        const uint32_t nib = (w >> (4 * (lane & 7))) & 15u;
-        v = 0xC0C0C0C0u ^ (((nib * 0x00204081u) & 0x01010101u) << 7);
+        v = fp4_of_4bits((w >> (4 * (lane & 7))) & 15u);
     }
-    *(uint32_t *)(out + (size_t)row * 256 + 4 * lane) = v;
+    *(uint16_t *)(out + (size_t)row * SS_X_ROW + 2 * lane) = (uint16_t)v;
 }
 
 /* raw local match of a database shard -> the 8-byte records ranks exchange (include/sendslam_orb.h ss_match_part) */

@@ -15,6 +15,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
 SS_MAX_LEVELS = 16
+EXPANDED_ROW_BYTES = 128  # one FP4 value (+1 / -1) per descriptor bit
 ABI_VERSION = 3
 
 SS_OK = 0
@@ -326,8 +327,8 @@ class OrbContext:
 
     @staticmethod
     def expanded_bytes(n: int) -> int:
-        """bytes of n descriptors in the matrix-core matcher's operand format (256 B per row, rows rounded up to 32)"""
-        return ((n + 31) & ~31) * 256
+        """bytes of n descriptors in the matrix-core matcher's operand format (128 B per row, rows rounded up to 32)"""
+        return ((n + 31) & ~31) * EXPANDED_ROW_BYTES
 
     def expand_descriptors_device(self, d_packed: int, n: int, d_expanded: int):
         self._check(self._lib.ss_expand_descriptors_device(self._h, C.c_void_p(d_packed), n, C.c_void_p(d_expanded)))

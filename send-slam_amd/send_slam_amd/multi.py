@@ -119,10 +119,10 @@ def hip_local_match(ctx) -> LocalMatch:
 
 
 def expand_database(ctx, db_slab: torch.Tensor) -> torch.Tensor:
-    """A rank's database slab (u8 [n, 32]) in the matrix-core matcher's operand format (u8 [n rounded up to 32, 256]),
+    """A rank's database slab (u8 [n, 32]) in the matrix-core matcher's operand format (u8 [n rounded up to 32, 128]),
     prepared ONCE: the per-query match then expands nothing (ss_expand_descriptors_device)."""
     n = db_slab.shape[0]
-    out = torch.empty((ctx.expanded_bytes(n) // 256, 256), dtype=torch.uint8, device=db_slab.device)
+    out = torch.empty((ctx.expanded_bytes(n) // 128, 128), dtype=torch.uint8, device=db_slab.device)
     with on_ctx_stream(ctx, db_slab.device):
         ctx.expand_descriptors_device(db_slab.data_ptr(), n, out.data_ptr())
     ctx.synchronize()
@@ -147,9 +147,9 @@ def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, s
                 dist.broadcast(query, src=src)
         part = torch.empty(nq, dtype=torch.int64, device=dev)  # nq x ss_match_part (8 B)
         if db_expanded is not None:
-            # the slab was expanded once (expand_database); the query is expanded per call (nq x 256 B)
+            # the slab was expanded once (expand_database); the query is expanded per call (nq x 128 B)
             nt = db_slab.shape[0] if n_db is None else n_db
-            qx = torch.empty((ctx.expanded_bytes(nq) // 256, 256), dtype=torch.uint8, device=dev)
+            qx = torch.empty((ctx.expanded_bytes(nq) // 128, 128), dtype=torch.uint8, device=dev)
             ctx.expand_descriptors_device(query.data_ptr(), nq, qx.data_ptr())
             ctx.match_partial_expanded_device(qx.data_ptr(), nq, db_expanded.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
         else:

@@ -266,13 +266,14 @@ def test_expanded_operands_match_equals_oracle(oracle, nq, nt):
     d2 = torch.empty(nq, dtype=torch.int16, device=dev)
     with binding.OrbContext(0) as ctx:
         qx = torch.empty(ctx.expanded_bytes(nq), dtype=torch.uint8, device=dev)
-        tx = torch.empty(max(ctx.expanded_bytes(nt), 256), dtype=torch.uint8, device=dev)
+        tx = torch.empty(max(ctx.expanded_bytes(nt), 128), dtype=torch.uint8, device=dev)
         ctx.expand_descriptors_device(tq.data_ptr(), nq, qx.data_ptr())
         ctx.expand_descriptors_device(tt.data_ptr() if nt else 0, nt, tx.data_ptr())
         ctx.synchronize()
-        x = qx.cpu().numpy()[:nq * 256].reshape(nq, 256)
-        bits = np.unpackbits(q, axis=1, bitorder="little")
-        assert np.array_equal(x, np.where(bits == 1, 0x40, 0xC0).astype(np.uint8))
+        x = qx.cpu().numpy()[:nq * 128].reshape(nq, 128)
+        bits = np.unpackbits(q, axis=1, bitorder="little")  # bit b -> nibble b: FP4 +1.0 = 0x2, -1.0 = 0xA
+        nib = np.where(bits == 1, 0x2, 0xA).astype(np.uint8)
+        assert np.array_equal(x, nib[:, 0::2] | (nib[:, 1::2] << 4))
         for kw in (dict(th=50, ratio_num=9), dict(th=-1, ratio_num=1)):
             ctx.match_expanded_device(qx.data_ptr(), nq, tx.data_ptr(), nt, idx.data_ptr(), d1.data_ptr(), d2.data_ptr(), **kw)
             ctx.synchronize()
