@@ -272,6 +272,10 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 }
 
 #define FT_THREADS (8 * SS_TILE_H2)
+#ifndef FT_SKIP
+#define FT_SKIP 0 /* accounting builds only (profiles/tools/fast_accounting.sh; results invalid): 1 halo ring, 2 blur H,
+                   * 4 arc search, 8 NMS, 16 blur V, 32 compass + queue */
+#endif
 __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__restrict__ pyr,
                                                     uint8_t *__restrict__ score,
                                                     const ss_geom *__restrict__ g,
@@ -309,6 +313,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const uint8_t *img = inplace ? lvl0 + (int64_t)frame * lvl0_fs : pyr + fb;
     const int ipitch = inplace ? lvl0_pitch : pitch;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#if defined(FT_EXP) && FT_EXP == 1 /* timing experiment: every interior tile stages the same (cache-hot) pixels */
+#define FT_EXP_HOT 1
+#endif
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
@@ -331,7 +338,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const bool interior = inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h;
     if (interior) {
         /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
+#ifdef FT_EXP_HOT
+        const uint8_t *tile0 = img + (size_t)60 * ipitch + 60;
+#else
         const uint8_t *tile0 = img + (size_t)(y0 - 4) * ipitch + (x0 - 4);
+#endif
         const uint32_t off = __umul24((uint32_t)ty, (uint32_t)ipitch) + 4u * (uint32_t)tx;
 #pragma unroll
         for (int rr = 0; rr < 3; rr++) {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     uint32_t cand_bits = 0;
     const i16x2 th2 = as_i16x2((uint32_t)min_th * 0x00010001u);
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) { /* two rows per thread */
+    for (int rr = 0; rr < ((FT_SKIP & 32) ? 0 : 2); rr++) { /* two rows per thread */
         const int ly = 2 * ty + rr;
         /* two pixels per operation: ring values go to the 16-bit halves of a dword (v_perm_b32),
          * differences and the min/max tree are v_pk_*_i16 */
@@ -424,9 +435,25 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             }
         cand_bits &= ok;
     }
-    if (cand_bits) { /* rare: a few % of the pixels.  One LDS atomic per lane reserves its slots (the queue is unordered) */
-        uint32_t slot = atomicAdd(&n_list, (int)__popc(cand_bits));
+    /* Queue slots: a wave-wide inclusive scan of the lanes' candidate counts by six DPP additions, ONE LDS atomic per
+     * wave for the block-wide base (the queue is unordered).  Left to the compiler, atomicAdd(&n_list, popc) of a
+     * non-uniform value becomes a scalar loop over the active lanes (eight instructions per lane with a candidate). */
+    if (__ballot(cand_bits != 0) != 0) {
+        const int cnt = (int)__popc(cand_bits);
+        int incl = cnt;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false); /* row_bcast15 -> rows 1, 3 */
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false); /* row_bcast31 -> rows 2, 3 */
+        const int total = __builtin_amdgcn_readlane(incl, 63); /* lane 63 holds the wave's total */
+        int base = 0;
+        if (lane_id() == 0) base = atomicAdd(&n_list, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        uint32_t slot = (uint32_t)(base + incl - cnt);
         const uint32_t code0 = (uint32_t)(((2 * ty + 1) << 8) | (4 * tx + 1));
+        if (cand_bits)
         do {
             const uint32_t bit = (uint32_t)__builtin_ctz(cand_bits);
             cand_bits &= cand_bits - 1;
@@ -434,7 +461,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         } while (cand_bits);
     }
     /* the same test for the 1-px ring around the tile (scores the NMS of the edge pixels needs) */
-    if (threadIdx.x < FT_HALO_PIXELS) {
+    if (!(FT_SKIP & 1) && threadIdx.x < FT_HALO_PIXELS) {
         const int i = threadIdx.x;
         int lx, ly;
         if (i < SS_TILE_W + 2) { lx = i - 1; ly = -1; }
@@ -452,7 +479,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     }
     /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
      * window [x-3, x+4] */
-    {
+    if (!(FT_SKIP & 2)) {
         constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
         constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
         /* one item = four pixels of the two rows of a pair: 16 dot products, ONE 16-byte LDS store */
@@ -481,7 +508,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int RDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
     uint8_t *out8 = (uint8_t *)&out_tile[0][0];
-    const int n = n_list;
+    const int n = (FT_SKIP & 4) ? 0 : n_list;
     for (int e = threadIdx.x; e < n; e += FT_THREADS) {
         const int ly = (int)(list[e] >> 8) - 1, lx = (int)(list[e] & 0xFF) - 1;
         const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
@@ -516,7 +543,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * joins the sub-list of its cell window (a tile meets at most 3 x 2 of them); its slot comes
      * from an LDS counter, so no global atomic is involved: pass 1 here allots the slots, pass 2
      * (after the blur's vertical pass) knows the sub-list offsets and writes the records. */
-    const int nc = n_corner, ini_th = g->ini_th;
+    const int nc = (FT_SKIP & 8) ? 0 : n_corner, ini_th = g->ini_th;
     const uint32_t tc = tr[9];
     const int col0 = (int)(tc & 0xFFFFu), row0 = (int)(tc >> 16);
     for (int e = threadIdx.x; e < nc; e += FT_THREADS) {
@@ -549,7 +576,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
 
     /* K6a vertical pass, two output rows per thread (rows 2ty and 2ty+1 read the same four row
      * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path */
-    {
+    if (!(FT_SKIP & 16)) {
         constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
         constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
         constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
