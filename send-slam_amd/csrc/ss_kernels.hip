@@ -73,6 +73,13 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* K0: ingest.  channels == 1: pitched copy; 3/4: fixed-point gray, c0/c1/c2 = weights of   */
 /* byte 0/1/2 (host swaps RY/BY with the calibration's rgb flag).  4 pixels per thread.    */
@@ -153,10 +160,18 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
     *(uint32_t *)(base + D.off + (size_t)dy * D.pitch + dx4) = out;
 }
 
-/* LDS-staged form of the same step for pyramid scale factors <= 1.4 (the source window of a
- * 64x64 destination tile then fits 96 B x 80 rows): the window is staged with coalesced dword
- * loads, the taps are LDS byte reads -- 6 global memory instructions per 4 output pixels
- * instead of 21. */
+/* LDS-staged, separable form of the same step for pyramid scale factors <= 1.4 (the source window of a 64x64
+ * destination tile then fits 96 B x 80 rows).  cv::resize's 8-bit linear path is two passes with a rounding in between:
+ * h = S[s0] * a0 + S[s1] * a1 per source row, then ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 >> 2.  Every
+ * source row serves two destination rows, so the horizontal sums are formed ONCE per source row (78 rows for 64
+ * destination rows at 1.2) and kept in LDS as h >> 4 (16 bits):
+ *   pass 1  thread = four destination columns x every 16th source row.  The <= 8 source bytes of the four columns are
+ *           12 staged bytes funnelled to 8 (two v_alignbyte); one v_perm_b32 per column picks its two taps' bytes into
+ *           16-bit halves and one v_dot2_u32_u16 multiplies them by (a0, a1): two instructions per sum, no byte loads,
+ *           no per-tap address.  s1 = s0 + 1 wherever a1 != 0 (ss_geometry.cpp build_axis_table).
+ *   pass 2  thread = four destination columns x four destination rows: two 8-byte LDS reads per row, products on the
+ *           24-bit multiplier with SDWA half-word operands.
+ * 15 VALU lane-operations per pixel against 26 for the one-pass form that formed every h twice. */
 #define RS_TILE_H 64
 #define RS_ROWS 80 /* 64 * 1.2 + 2 rounded up */
 #define RS_WORDS 24
@@ -165,8 +180,9 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
                                                     const ss_rtab *__restrict__ rtab, int level,
                                                     const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
-    __shared__ uint32_t lds[RS_ROWS][RS_WORDS];
-    __shared__ ss_rtab xt[SS_TILE_W], yt[RS_TILE_H];
+    __shared__ uint32_t lds[RS_ROWS + 1][RS_WORDS]; /* + 1: a funnel may read one dword past the last row's window */
+    __shared__ __attribute__((aligned(8))) uint16_t hbuf[RS_ROWS][SS_TILE_W];
+    __shared__ ss_rtab yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
     const ss_level &S = g->lv[level - 1];
     const int tiles_x = (D.w + SS_TILE_W - 1) / SS_TILE_W;
@@ -176,13 +192,15 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     const bool inplace = level == 1 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
     const uint8_t *src = inplace ? lvl0 + (int64_t)blockIdx.y * lvl0_fs : base + S.off;
     const int spitch = inplace ? lvl0_pitch : S.pitch;
-    /* the tile's tap tables go to LDS too (x table is padded past w; y rows are clamped) */
-    if (threadIdx.x < SS_TILE_W) xt[threadIdx.x] = rtab[D.xtab_off + x0 + threadIdx.x];
-    else if (threadIdx.x < SS_TILE_W + RS_TILE_H) yt[threadIdx.x - SS_TILE_W] = rtab[D.ytab_off + imin(y0 + (int)threadIdx.x - SS_TILE_W, D.h - 1)];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    /* this thread's four columns: taps straight to registers (x table is padded past w); row taps of the tile to LDS */
+    ss_rtab rx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rx[i] = rtab[D.xtab_off + x0 + 4 * tx + i];
+    if (threadIdx.x < RS_TILE_H) yt[threadIdx.x] = rtab[D.ytab_off + imin(y0 + (int)threadIdx.x, D.h - 1)];
     const int gx0 = (int)rtab[D.xtab_off + x0].s0 & ~3;      /* first source byte, dword aligned */
     const int gy0 = (int)rtab[D.ytab_off + imin(y0, D.h - 1)].s0;
     const int gy1 = (int)rtab[D.ytab_off + imin(y0 + RS_TILE_H - 1, D.h - 1)].s1; /* last source row used */
-
     {
         /* all of a thread's loads first, then the LDS stores: one memory latency instead of one per round */
         constexpr int ROUNDS = (RS_ROWS * RS_WORDS + 255) / 256;
@@ -201,31 +219,48 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
             if (idx < RS_ROWS * RS_WORDS) (&lds[0][0])[idx] = v[it];
         }
     }
+    /* pass 1 constants: dword b of the window row holds the first column's s0; the funnel {B:A} = 8 bytes from byte
+     * o0 = s0[0] - gx0 on; column i reads funnel bytes k, k + 1 (k = s0[i] - s0[0] <= 6) as two 16-bit halves */
+    const int o0 = (int)rx[0].s0 - gx0, bword = o0 >> 2;
+    const uint32_t fsh = (uint32_t)o0 & 3u;
+    uint32_t sel[4], taps[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k = (uint32_t)((int)rx[i].s0 - (int)rx[0].s0);
+        sel[i] = 0x0C000C00u | k | ((k + 1) << 16);
+        taps[i] = (uint32_t)(uint16_t)rx[i].a0 | ((uint32_t)(uint16_t)rx[i].a1 << 16);
+    }
     __syncthreads();
-
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n_rows = gy1 - gy0 + 1;
+#pragma unroll
+    for (int rr = 0; rr < RS_ROWS / 16; rr++) {
+        const int r = ty + 16 * rr;
+        if (r >= n_rows) break;
+        const uint32_t *w = &lds[r][bword];
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        const uint32_t fa = __builtin_amdgcn_alignbyte(d1, d0, fsh), fb = __builtin_amdgcn_alignbyte(d2, d1, fsh);
+        uint32_t hs[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) hs[i] = dot2_u16(__builtin_amdgcn_perm(fb, fa, sel[i]), taps[i], 0u) >> 4; /* < 2^16 */
+        *(uint2 *)&hbuf[r][4 * tx] = make_uint2(hs[0] | (hs[1] << 16), hs[2] | (hs[3] << 16));
+    }
+    __syncthreads();
     const int dx4 = x0 + 4 * tx;
     if (dx4 >= D.w) return;
-    ss_rtab rx[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) rx[i] = xt[4 * tx + i];
 #pragma unroll
     for (int rr = 0; rr < RS_TILE_H / 16; rr++) {
         const int ly = ty + 16 * rr, dy = y0 + ly;
         if (dy >= D.h) break;
         const ss_rtab ry = yt[ly];
-        const uint8_t *l0 = (const uint8_t *)&lds[ry.s0 - gy0][0] - gx0;
-        const uint8_t *l1 = (const uint8_t *)&lds[ry.s1 - gy0][0] - gx0;
+        const uint2 h0 = *(const uint2 *)&hbuf[ry.s0 - gy0][4 * tx], h1 = *(const uint2 *)&hbuf[ry.s1 - gy0][4 * tx];
         const int b0 = ry.a0, b1 = ry.a1;
+        const uint32_t p0[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+        const uint32_t p1[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            /* every factor is below 2^12 (taps), 2^8 (pixels) or 2^16 (h >> 4): the 24-bit multiplier (full rate) gives
-             * the same products as the 32-bit one (quarter rate) */
-            const int h0 = __mul24((int)l0[rx[i].s0], (int)rx[i].a0) + __mul24((int)l0[rx[i].s1], (int)rx[i].a1);
-            const int h1 = __mul24((int)l1[rx[i].s0], (int)rx[i].a0) + __mul24((int)l1[rx[i].s1], (int)rx[i].a1);
-            /* h >> 4 < 2^16 (the & is a no-op that lets the compiler see it: one v_bfe_u32, then the 24-bit multiplier) */
-            const int v = ((__mul24(b0, (int)(((uint32_t)h0 >> 4) & 0xFFFFu)) >> 16) + (__mul24(b1, (int)(((uint32_t)h1 >> 4) & 0xFFFFu)) >> 16) + 2) >> 2;
+            /* every factor is below 2^12 (taps) or 2^16 (h >> 4): the 24-bit multiplier gives the 32-bit products */
+            const int v = ((__mul24(b0, (int)p0[i]) >> 16) + (__mul24(b1, (int)p1[i]) >> 16) + 2) >> 2;
             out |= ((uint32_t)v & 0xFFu) << (8 * i);
         }
         *(uint32_t *)(base + D.off + (__umul24((uint32_t)dy, (uint32_t)D.pitch) + (uint32_t)dx4)) = out;
@@ -264,12 +299,6 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p < 0 ? 0 : (p >= n ? n - 1 : p);
 }
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
-{
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
-}
 
 #define FT_THREADS (8 * SS_TILE_H2)
 #ifndef FT_SKIP
