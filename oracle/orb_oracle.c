@@ -813,7 +813,10 @@ int orc_extract(const uint8_t *gray, int w, int h, int stride, const orc_params 
         orc_point *cand = (orc_point *)malloc(sizeof(orc_point) * (size_t)max_cand);
         const int nc = orc_candidates(levels[l], lw, lh, p->ini_th_fast, p->min_th_fast, cand, max_cand);
         if (nc < 0) { rc = -2; free(cand); break; }
-        const int cap = g.quota[l] + 8 > nc ? nc + 8 : g.quota[l] + 8;
+        /* DistributeOctTree stops at the first pass that reaches N nodes, and a pass may quadruple the node count
+         * (wide level, small quota: 7 root nodes -> 28 leaves for N = 15): up to 4 N + 4 n_ini nodes, never more than
+         * there are candidates */
+        const int cap = nc + 8;
         lvl_pts[l] = (orc_point *)malloc(sizeof(orc_point) * (size_t)(cap > 0 ? cap : 1));
         int nk = 0;
         if (nc > 0) {

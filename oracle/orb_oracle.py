@@ -170,7 +170,7 @@ def extract(img: np.ndarray, p: Params):
     """-> (keypoints KP_DTYPE[n], descriptors u8[n,32], level_counts int[n_levels])"""
     img = np.ascontiguousarray(img)
     h, w = img.shape
-    cap = p.n_features + 16 * p.n_levels
+    cap = 4 * p.n_features + 64 * p.n_levels  # a level may return up to 4 x its quota (orb_oracle.c, orc_extract)
     kps = np.empty(cap, KP_DTYPE)
     desc = np.empty((cap, 32), np.uint8)
     counts = (C.c_int * MAX_LEVELS)()

@@ -634,3 +634,15 @@ def test_contexts_do_not_leak_device_memory():
             ctx.match(np.zeros((10, 32), np.uint8), np.zeros((300000, 32), np.uint8))
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 25 contexts"
+
+
+def test_quadtree_first_pass_overshoot_vs_oracle(oracle):
+    """Found by the soak sweep (seed 20262, case 1339): more keypoints than quota + 3 at a wide level -- upstream keeps
+    them all; so do the oracle and the device (capacities sized for 4 x the root nodes)."""
+    from test_oracle_units import wide_overshoot_case
+    img, kw = wide_overshoot_case()
+    with binding.OrbContext(0, **kw) as ctx:
+        kps, desc, counts = ctx.extract(img)
+    okps, odesc, ocounts = oracle.extract(img, oracle.default_params(**kw))
+    assert np.array_equal(counts, ocounts) and counts.sum() > 85
+    assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)

@@ -278,3 +278,22 @@ def test_python_introsort_port_agrees_and_killer_reaches_heapsort(oracle):
     k = np.array(pyref.quicksort_killer(500))
     oracle.std_sort(k + 2, np.zeros(500, int))
     assert heap_calls.value > before
+
+
+def wide_overshoot_case():
+    """A wide, low image with a small quota: 7 root nodes at the top level quadruple to 28 leaves in the first pass
+    although the quota is 15: DistributeOctTree stops at the first pass that reaches N, it does not trim."""
+    rng = np.random.default_rng(99)
+    img = synth.frame(77, 881, 176).astype(np.int32) + rng.integers(-25, 26, size=(176, 881))
+    return np.clip(img, 0, 255).astype(np.uint8), dict(n_features=85, n_levels=4, scale_factor=1.25)
+
+
+def test_quadtree_first_pass_may_overshoot_the_quota(oracle):
+    img, kw = wide_overshoot_case()
+    p = oracle.default_params(**kw)
+    g = oracle.geometry(p, 881, 176)
+    kps, desc, counts = oracle.extract(img, p)
+    quota = [g.quota[l] for l in range(4)]
+    assert any(c > q + 3 for c, q in zip(counts, quota)), (list(counts), quota)
+    assert all(c <= max(q + 3, 4 * int(round((g.w[l] - 32) / (g.h[l] - 32)))) for l, (c, q) in enumerate(zip(counts, quota)))
+    assert len(kps) == counts.sum() > 85
