@@ -49,6 +49,10 @@ struct ss_ctx {
     std::string err;
     bool calibrated = false;
     bool force_ingest = false; /* SENDSLAM_FORCE_INGEST=1: always copy level 0 into the pyramid block (tests) */
+    int skip_after = 0, n_extracts = 0; /* SENDSLAM_SKIP_AFTER=k: the mask applies from the k-th batch of the context on, and the
+                                * per-level state of the batch before is kept (so that what follows a skipped stage still has work) */
+    int skip_stages = 0;       /* SENDSLAM_SKIP_STAGES bit mask, timing experiments only (results invalid): 1 quadtree, 2 orient_describe,
+                                * 4 resize, 8 fast_blur_nms, 16 gather + emit, 32 match */
     bool no_desc_x = false;    /* SENDSLAM_MATCH_PACKED=1: batch matches run k_match_mfma on the packed descriptors (A/B tests) */
     ss_camera cam{};
     int cam_id = 0;
@@ -278,7 +282,13 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
     int64_t all_px = 0;
     for (int l = 0; l < g.n_levels; l++) all_px += level_px(g, l);
 
-    HIP_TRY(c, hipMemsetAsync(c->state, 0, (size_t)n * SS_MAX_LEVELS * sizeof(ss_level_state), s));
+#ifdef SS_TIMING_KNOBS /* profiles/tools/build_variant.sh only: the shipped library has no way to skip a stage */
+    const int skip_mask = c->n_extracts++ >= c->skip_after ? c->skip_stages : 0;
+#else
+    const int skip_mask = 0;
+#endif
+    if (!(skip_mask && c->skip_after > 0))
+        HIP_TRY(c, hipMemsetAsync(c->state, 0, (size_t)n * SS_MAX_LEVELS * sizeof(ss_level_state), s));
     /* A 1-channel image whose base, rows and frames are 16-byte aligned IS pyramid level 0: the kernels read it in
      * place (aligned dword loads work on it as they do on the pyramid block) and the ingest copy is skipped.  The
      * caller's buffer must stay untouched until the batch has finished (it is asynchronous, as before). */
@@ -301,25 +311,25 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         stage_timer t(c, "ingest", n * level_px(g, 0) * (channels + 1));
         ssk_ingest(s, d_pix, channels, row_stride, frame_stride, c0, c1, c2, c->pyr, c->dg, g, n);
     }
-    for (int l = 1; l < g.n_levels; l++) {
+    for (int l = 1; l < g.n_levels && !(skip_mask & 4); l++) {
         stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
         ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n, l0);
     }
-    {
+    if (!(skip_mask & 8)) {
         /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map and the
          * survivor lists are this design's own intermediates) */
         stage_timer t(c, "fast_blur_nms", n * 2 * all_px);
         ssk_fast_blur_nms(s, c->pyr, c->score, c->blur, c->dg, g, c->d_tiles2, c->d_cinfo, c->tsurv, c->thdr, c->state, n, l0);
     }
-    {
+    if (!(skip_mask & 16)) {
         stage_timer t(c, "bucket_gather", 0);
         ssk_bucket_gather(s, c->dg, g, c->d_cell_units, c->tsurv, c->thdr, c->bucket, c->cell_cnt, c->state, n);
     }
-    {
+    if (!(skip_mask & 16)) {
         stage_timer t(c, "cells_emit", 0);
         ssk_cells_emit(s, c->bucket, c->dg, g, c->cell_cnt, c->cand, c->state, n);
     }
-    {
+    if (!(skip_mask & 1)) {
         stage_timer t(c, "quadtree", 0);
         ssk_quadtree(s, c->dg, g, c->cand, c->qbuf0, c->qbuf1, c->nodes, c->lists, c->sel, c->state, n);
     }
@@ -327,7 +337,7 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         stage_timer t(c, "slots", 0);
         ssk_slots(s, c->dg, c->sel, c->state, c->kp_ref, c->n_kp, c->level_counts, c->frame_error, n);
     }
-    {
+    if (!(skip_mask & 2)) {
         stage_timer t(c, "orient_describe", (int64_t)n * g.n_features * (709 + 512 + 32 + 24));
         ssk_orient_describe(s, c->dg, g, c->pyr, c->blur, c->sel, c->kp_ref, c->n_kp, c->kps, c->desc, n, l0, c->params.steer_fma != 0, c->desc_x);
     }
@@ -411,6 +421,10 @@ int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
     c->params = p;
     if (const char *e = getenv("SENDSLAM_FORCE_INGEST")) c->force_ingest = atoi(e) != 0;
     if (const char *e = getenv("SENDSLAM_MATCH_PACKED")) c->no_desc_x = atoi(e) != 0;
+#ifdef SS_TIMING_KNOBS
+    if (const char *e = getenv("SENDSLAM_SKIP_STAGES")) c->skip_stages = atoi(e);
+    if (const char *e = getenv("SENDSLAM_SKIP_AFTER")) c->skip_after = atoi(e);
+#endif
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete c;
@@ -648,7 +662,12 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n * n_chunks * kcap * SSK_MATCH_PARTIAL_BYTES);
         if (rc != SS_OK) return rc;
     }
-    {
+#ifdef SS_TIMING_KNOBS
+    const bool skip_match = ((c->n_extracts > c->skip_after ? c->skip_stages : 0) & 32) != 0;
+#else
+    const bool skip_match = false;
+#endif
+    if (!skip_match) {
         const int64_t nf = c->hg.n_features;
         stage_timer t(c, "match", (int64_t)n * (nf * 32 * 2 + nf * 8));
         if (c->desc_x)
