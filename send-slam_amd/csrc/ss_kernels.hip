@@ -34,6 +34,8 @@
 #include "ss_layout.h"
 
 #define WAVE 64
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
 
 namespace {
 
@@ -74,6 +76,11 @@ __device__ __forceinline__ int wave_sum(int v)
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
 
 __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -284,9 +291,45 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 /* unordered bucket per cell serves both thresholds: the cell's count word holds the number */
 /* of survivors (low half, = bucket slot allocator) and of those >= iniTh (high half).      */
 /* ------------------------------------------------------------------------------------ */
+#ifndef FT_BLUR_MFMA
+/* 1: the horizontal Gaussian on the matrix pipe.  Bit-exact and 4 % fewer vector instructions in k_fast_score, but measured
+ * SLOWER where it counts: alone 0.336 vs 0.337 ms per 64 frames, four batches in flight 100.3 k vs 101.8 k frames/s (the
+ * 128 cycles of the two MFMAs sit in every wave's critical path and the pipe is shared with the matcher).  Kept as the
+ * record of that experiment (profiles/tools/build_variant.sh mfmah -DFT_BLUR_MFMA=1). */
+#define FT_BLUR_MFMA 0
+#endif
+#if FT_BLUR_MFMA
+/* K6a on the matrix pipe: the 7-tap horizontal Gaussian of 32 rows x 32 columns is two v_mfma_i32_32x32x32_i8 (k-steps) of
+ * the staged bytes -- A: row i, 64 bytes from pixel x0 - 8 + 32 N on, as int8 = pixel - 128 -- with a constant band
+ * matrix, B[k][n] = tap k - n - 5 of output column n (byte k of that window is pixel x0 - 8 + 32 N + k, output
+ * column n is pixel x0 + 32 N + n).  Lane (n, half) of either operand carries k = 32 s + 16 half .. + 15 in k-step s.
+ * The taps sum to 256, so D = (8.8 fixed-point sum) - 32768: exactly the int16 the vertical pass reads (v_dot2_i32_i16),
+ * which adds the 256 * 32768 back through its accumulator constant. */
+struct blur_band { uint32_t w[2][64][4]; };
+constexpr blur_band make_blur_band()
+{
+    blur_band t{};
+    constexpr int taps[7] = {SS_GAUSS_K0, SS_GAUSS_K1, SS_GAUSS_K2, SS_GAUSS_K3, SS_GAUSS_K2, SS_GAUSS_K1, SS_GAUSS_K0};
+    for (int st = 0; st < 2; st++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int b = 0; b < 16; b++) {
+                const int n = lane & 31, k = 32 * st + 16 * (lane >> 5) + b, t7 = k - n - 5;
+                if (t7 >= 0 && t7 < 7) t.w[st][lane][b >> 2] |= (uint32_t)taps[t7] << (8 * (b & 3));
+            }
+    return t;
+}
+__device__ const blur_band g_blur_band = make_blur_band();
+static_assert(SS_GAUSS_K0 * 2 + SS_GAUSS_K1 * 2 + SS_GAUSS_K2 * 2 + SS_GAUSS_K3 == 256 && SS_GAUSS_K3 < 128, "taps: int8, sum 256");
+#endif
+
 #define FT_ROWS (SS_TILE_H2 + 8)        /* staged rows: y0 - 4 .. y0 + 35 */
 #define FT_BLUR_ROWS (SS_TILE_H2 + 6)   /* of which the blur uses y0 - 3 .. y0 + 34 */
-#define FT_WORDS (SS_TILE_W / 4 + 2)    /* staged bytes: x0 - 4 .. x0 + 67 */
+#define FT_WORDS (SS_TILE_W / 4 + 8)    /* staged bytes: x0 - 16 .. x0 + 79, of which x0 - 4 .. x0 + 67 are used: 16-byte
+                                         * aligned rows, so an interior tile is staged by ONE 16-byte load per thread, and a
+                                         * 24-dword pitch, on which the four rows a wave reads at once share no bank */
+#define FT_XB 16                        /* staged byte of the tile's first pixel */
+#define FT_XW (FT_XB / 4)
+#define FT_OWORDS (SS_TILE_W / 4 + 2)   /* score tile: bytes x0 - 4 .. x0 + 67 */
 #define FT_HALO_PIXELS (2 * (SS_TILE_W + 2) + 2 * SS_TILE_H2)
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -317,12 +360,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
                                                     const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
     /* `score` may be NULL: no later kernel reads the response map (it exists for stage-by-stage tests) */
-    /* horizontal Gaussian sums (u16, 8 fractional bits), packed as (row 2p, row 2p+1) per pixel
-     * so the vertical pass is four v_dot2_u32_u16 per output */
+    /* horizontal Gaussian sums (8 fractional bits, less 32768: int16), packed as (row 2p, row 2p+1) per pixel
+     * so the vertical pass is four v_dot2_i32_i16 per output */
     __shared__ __attribute__((aligned(16))) uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
-    __shared__ uint32_t lds[FT_ROWS][FT_WORDS];
+    /* + 1 row: the blur's A operand of the last row / last 16 columns reads up to 40 bytes past it (against zero taps) */
+    __shared__ __attribute__((aligned(16))) uint32_t lds[FT_ROWS + 1][FT_WORDS];
     /* scores of the tile and of its 1-px ring: row ly + 1, byte lx + 4 (tile pixels dword-aligned) */
-    __shared__ __attribute__((aligned(16))) uint32_t out_tile[SS_TILE_H2 + 2][FT_WORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t out_tile[SS_TILE_H2 + 2][FT_OWORDS];
     __shared__ uint16_t list[SS_TILE_W * SS_TILE_H2 + FT_HALO_PIXELS + 4];
     __shared__ uint16_t corners[SS_TILE_W * SS_TILE_H2];
     __shared__ uint16_t xinf[SS_TILE_W], yinf[SS_TILE_H2];
@@ -348,8 +392,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
 
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
-    static_assert(((SS_TILE_H2 + 2) * FT_WORDS) % 4 == 0 && ((SS_TILE_H2 + 2) * FT_WORDS) / 4 <= FT_THREADS, "out_tile is cleared by one 16-byte store per thread");
-    if (threadIdx.x < (SS_TILE_H2 + 2) * FT_WORDS / 4) ((uint4 *)&out_tile[0][0])[threadIdx.x] = make_uint4(0, 0, 0, 0);
+    static_assert(((SS_TILE_H2 + 2) * FT_OWORDS) % 4 == 0 && ((SS_TILE_H2 + 2) * FT_OWORDS) / 4 <= FT_THREADS, "out_tile is cleared by one 16-byte store per thread");
+    if (threadIdx.x < (SS_TILE_H2 + 2) * FT_OWORDS / 4) ((uint4 *)&out_tile[0][0])[threadIdx.x] = make_uint4(0, 0, 0, 0);
     /* window info of the tile's columns / rows: requested now, stored to LDS after the staging loads have been issued,
      * so that the block waits for the two kinds of loads once, not one after the other */
     uint16_t cinf_v = 0;
@@ -358,29 +402,25 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         const int k = (int)threadIdx.x - SS_TILE_W;
         cinf_v = y0 + k < h ? cinfo[yinfo_off + y0 + k] : (uint16_t)0;
     }
-    /* stage rows y0-4 .. y0+35, bytes x0-4 .. x0+67 as aligned dwords: thread (tx, ty) takes
-     * column tx of rows ty, ty+16, ty+32; the two rightmost columns go to tx < 2.  Pixels outside
+    /* stage rows y0-4 .. y0+35, bytes x0-4 .. x0+67 (inside 96-byte rows that start at x0-16).  Pixels outside
      * the image are filled by BORDER_REFLECT_101 (what the blur needs; FAST never evaluates a
-     * pixel whose ring leaves the image, so it does not care).  Rows are always reflected (4
-     * ops); columns only in the tiles that touch the left / right image edge (block-uniform). */
+     * pixel whose ring leaves the image, so it does not care): only the tiles at the image rim
+     * take that path (block-uniform), as dwords: thread (tx, ty) takes column tx of rows ty, ty+16,
+     * ty+32; the two rightmost columns go to tx < 2. */
     const bool inner_x = x0 >= 4 && x0 + 68 <= w;
     const bool interior = inner_x && y0 >= 4 && y0 + SS_TILE_H2 + 4 <= h;
-    if (interior) {
-        /* interior tile (the common case): no reflection, one uniform base + a 32-bit lane offset */
+    /* rows start 16-byte aligned (levels: 64-byte pitch, 256-byte offsets; the caller's level 0: ss_api.cpp checks) */
+    if (interior && x0 >= FT_XB && x0 - FT_XB + 4 * FT_WORDS <= ipitch) {
+        /* interior tile (the common case): no reflection; thread t takes 16 bytes: row t / 6, bytes 16 (t % 6) */
+        static_assert(FT_ROWS * (FT_WORDS / 4) <= FT_THREADS, "one 16-byte load per thread stages the tile");
 #ifdef FT_EXP_HOT
-        const uint8_t *tile0 = img + (size_t)60 * ipitch + 60;
+        const uint8_t *tile0 = img + (size_t)60 * ipitch + 48;
 #else
-        const uint8_t *tile0 = img + (size_t)(y0 - 4) * ipitch + (x0 - 4);
+        const uint8_t *tile0 = img + (size_t)(y0 - 4) * ipitch + (x0 - FT_XB);
 #endif
-        const uint32_t off = __umul24((uint32_t)ty, (uint32_t)ipitch) + 4u * (uint32_t)tx;
-#pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            const int r = ty + (FT_THREADS / 16) * rr;
-            if (r < FT_ROWS) {
-                lds[r][tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * ipitch));
-                if (tx < 2) lds[r][16 + tx] = *(const uint32_t *)(tile0 + off + (uint32_t)((FT_THREADS / 16) * rr * ipitch) + 64);
-            }
-        }
+        const uint32_t r = __umulhi((uint32_t)threadIdx.x, 0xAAAAAAABu) >> 2, c = (uint32_t)threadIdx.x - 6u * r; /* t / 6 */
+        static_assert(FT_WORDS / 4 == 6, "t / 6 above");
+        if (r < FT_ROWS) *(uint4 *)&lds[r][4 * c] = *(const uint4 *)(tile0 + (__umul24(r, (uint32_t)ipitch) + 16u * c));
     } else {
         /* a tile at the image rim: rows by reflected row index; columns as the same aligned dwords wherever their
          * first byte is inside the row (a level's rows are padded to the pitch, the caller's rows to 16 bytes), and a
@@ -391,8 +431,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             if (r < FT_ROWS) {
                 const uint8_t *row = img + (size_t)reflect101(y0 - 4 + r, h) * ipitch;
                 const int gx = x0 - 4 + 4 * tx;
-                lds[r][tx] = (gx >= 0 && gx < w) ? *(const uint32_t *)(row + gx) : 0u;
-                if (tx < 2) lds[r][16 + tx] = (gx + 64 < w) ? *(const uint32_t *)(row + gx + 64) : 0u;
+                lds[r][FT_XW - 1 + tx] = (gx >= 0 && gx < w) ? *(const uint32_t *)(row + gx) : 0u;
+                if (tx < 2) lds[r][FT_XW + 15 + tx] = (gx + 64 < w) ? *(const uint32_t *)(row + gx + 64) : 0u;
             }
         }
         if (!inner_x) {
@@ -403,7 +443,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             for (int i = threadIdx.x; i < FT_ROWS * 6; i += FT_THREADS) {
                 const int r = i / 6, k = i - 6 * r;
                 const int x = k < 3 ? -1 - k : w + (k - 3), sx = k < 3 ? 1 + k : w - 2 - (k - 3);
-                const int bx = x - (x0 - 4), bs = sx - (x0 - 4);
+                const int bx = x - (x0 - FT_XB), bs = sx - (x0 - FT_XB);
                 if (bx >= 0 && bx < 4 * FT_WORDS && bs >= 0 && bs < 4 * FT_WORDS) t8[r * (4 * FT_WORDS) + bx] = t8[r * (4 * FT_WORDS) + bs];
             }
         }
@@ -423,13 +463,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * v_perm_b32 per row) */
     uint32_t cand_bits = 0;
     const i16x2 th2 = as_i16x2((uint32_t)min_th * 0x00010001u);
-#pragma unroll
-    for (int rr = 0; rr < ((FT_SKIP & 32) ? 0 : 2); rr++) { /* two rows per thread */
-        const int ly = 2 * ty + rr;
+    /* the four pixels of staged word wx of tile row ly (-1 .. SS_TILE_H2): verdicts in the top bits of the four bytes */
+    auto compass_row = [&](int ly, int wx) -> uint32_t {
         /* two pixels per operation: ring values go to the 16-bit halves of a dword (v_perm_b32),
          * differences and the min/max tree are v_pk_*_i16 */
-        const uint32_t u1 = lds[ly + 1][tx + 1], n1 = lds[ly + 7][tx + 1];
-        const uint32_t m0 = lds[ly + 4][tx], m1 = lds[ly + 4][tx + 1], m2 = lds[ly + 4][tx + 2];
+        const uint32_t *lw = &lds[0][0] + (ly + 4) * FT_WORDS + wx; /* flat: word -1 / 18 of a row is its neighbour row's */
+        const uint32_t u1 = lw[-3 * FT_WORDS], n1 = lw[3 * FT_WORDS];
+        const uint32_t m0 = lw[-1], m1 = lw[0], m2 = lw[1];
         uint32_t neg[2];
 #pragma unroll
         for (int pr = 0; pr < 2; pr++) { /* pixels 2pr, 2pr+1 of the thread's four */
@@ -449,7 +489,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             neg[pr] = __builtin_bit_cast(uint32_t, th2 - c); /* |c| <= 255: no wrap; negative <=> c > min_th */
         }
         /* bytes 1 and 3 of neg[0], then of neg[1]: their top bits are the four verdicts, in pixel order */
-        const uint32_t signs = __builtin_amdgcn_perm(neg[1], neg[0], 0x07050301u) & 0x80808080u;
+        return __builtin_amdgcn_perm(neg[1], neg[0], 0x07050301u) & 0x80808080u;
+    };
+#pragma unroll
+    for (int rr = 0; rr < ((FT_SKIP & 32) ? 0 : 2); rr++) { /* two rows per thread */
+        const uint32_t signs = compass_row(2 * ty + rr, tx + FT_XW);
         cand_bits |= rr ? signs : signs >> 4;
     }
     if (!interior) {
@@ -489,23 +533,70 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             list[slot++] = (uint16_t)(code0 + (bit >> 3) + ((bit & 4u) << 6)); /* (ly + 1) << 8 | (lx + 1) */
         } while (cand_bits);
     }
-    /* the same test for the 1-px ring around the tile (scores the NMS of the edge pixels needs) */
-    if (!(FT_SKIP & 1) && threadIdx.x < FT_HALO_PIXELS) {
+    /* the same test for the 1-px ring around the tile (scores the NMS of the edge pixels needs): the row above in wave 0,
+     * the row below in wave 1, the columns left and right in wave 2.  The ring's four corner pixels would cost a fourth
+     * wave the whole test: they are queued untested (phase 2 scores whatever is queued; the test only spares it work). */
+    static_assert(SS_TILE_W == 64 && 2 * SS_TILE_H2 <= 64 * (FT_THREADS / 64 - 2), "ring layout: one wave per row, the columns after them");
+    if (!(FT_SKIP & 1) && threadIdx.x < 2 * SS_TILE_W + 2 * SS_TILE_H2) {
         const int i = threadIdx.x;
         int lx, ly;
-        if (i < SS_TILE_W + 2) { lx = i - 1; ly = -1; }
-        else if (i < 2 * (SS_TILE_W + 2)) { lx = i - (SS_TILE_W + 2) - 1; ly = SS_TILE_H2; }
-        else if (i < 2 * (SS_TILE_W + 2) + SS_TILE_H2) { lx = -1; ly = i - 2 * (SS_TILE_W + 2); }
-        else { lx = SS_TILE_W; ly = i - 2 * (SS_TILE_W + 2) - SS_TILE_H2; }
+        if (i < SS_TILE_W) { lx = i; ly = -1; }
+        else if (i < 2 * SS_TILE_W) { lx = i - SS_TILE_W; ly = SS_TILE_H2; }
+        else if (i < 2 * SS_TILE_W + SS_TILE_H2) { lx = -1; ly = i - 2 * SS_TILE_W; }
+        else { lx = SS_TILE_W; ly = i - 2 * SS_TILE_W - SS_TILE_H2; }
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-            const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
+        if (interior || (x >= 3 && x < w - 3 && y >= 3 && y < h - 3)) {
+            const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + FT_XB + lx;
             const int v = c[0];
             const int p0 = c[3 * (FT_WORDS * 4)], p8 = c[-3 * (FT_WORDS * 4)], p4 = c[3], p12 = c[-3];
             const int dark = v - imax(imin(p0, p8), imin(p4, p12)), bright = imin(imax(p0, p8), imax(p4, p12)) - v;
             if (imax(dark, bright) > min_th) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
         }
+    } else if (!(FT_SKIP & 1) && threadIdx.x >= FT_THREADS - 4) {
+        const int k = (int)threadIdx.x - (FT_THREADS - 4);
+        const int lx = (k & 1) ? SS_TILE_W : -1, ly = (k & 2) ? SS_TILE_H2 : -1;
+        const int x = x0 + lx, y = y0 + ly;
+        if (interior || (x >= 3 && x < w - 3 && y >= 3 && y < h - 3)) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
     }
+#if FT_BLUR_MFMA
+    /* K6a horizontal pass on the same staged tile, on the matrix pipe (see g_blur_band): a wave takes 32 rows x 32 columns;
+     * the lane's sixteen sums are eight (row 2p, row 2p + 1) pairs of its column */
+    if (!(FT_SKIP & 2)) {
+        static_assert(SS_TILE_W == 64, "two 32-column blocks");
+        const int lane = lane_id(), wv = rfl((int)(threadIdx.x >> 6));
+        const int n = lane & 31, half = lane >> 5;
+        const v4i band0 = *(const v4i *)&g_blur_band.w[0][lane][0], band1 = *(const v4i *)&g_blur_band.w[1][lane][0];
+        constexpr int M_BLOCKS = (FT_BLUR_ROWS + 31) / 32;
+        for (int blk = wv; blk < 2 * M_BLOCKS; blk += FT_THREADS / 64) { /* wave-uniform */
+            const int m = blk >> 1, nb = blk & 1;
+            const int srow = imin(32 * m + n + 1, FT_ROWS - 1); /* blur row b = staged row b + 1 */
+            const uint8_t *src = tile8 + srow * (FT_WORDS * 4) + (FT_XB - 8) + 32 * nb + 16 * half;
+            const uint2 l0 = *(const uint2 *)src, h0 = *(const uint2 *)(src + 8), l1 = *(const uint2 *)(src + 32), h1 = *(const uint2 *)(src + 40);
+            constexpr uint32_t S = 0x80808080u;
+            const v4i a0 = v4i{(int)(l0.x ^ S), (int)(l0.y ^ S), (int)(h0.x ^ S), (int)(h0.y ^ S)};
+            const v4i a1 = v4i{(int)(l1.x ^ S), (int)(l1.y ^ S), (int)(h1.x ^ S), (int)(h1.y ^ S)};
+            v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, band0, v16i{0}, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, band1, d, 0, 0, 0);
+            /* lane (n, half): d[r] belongs to blur row 32 m + (r & 3) + 8 (r >> 2) + 4 half, column 32 nb + n */
+            uint32_t *dst = &hpair[16 * m + 2 * half][32 * nb + n];
+            if (32 * m + 32 <= FT_BLUR_ROWS) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    dst[(4 * j) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 1], (uint32_t)d[4 * j], 0x05040100u);
+                    dst[(4 * j + 1) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 3], (uint32_t)d[4 * j + 2], 0x05040100u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (16 * m + 4 * j >= FT_BLUR_ROWS / 2) break; /* wave-uniform: rows past the blur's window */
+                    const int pair = 16 * m + 4 * j + 2 * half;
+                    if (pair < FT_BLUR_ROWS / 2) dst[(4 * j) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 1], (uint32_t)d[4 * j], 0x05040100u);
+                    if (pair + 1 < FT_BLUR_ROWS / 2) dst[(4 * j + 1) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 3], (uint32_t)d[4 * j + 2], 0x05040100u);
+                }
+            }
+        }
+    }
+#else
     /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
      * window [x-3, x+4] */
     if (!(FT_SKIP & 2)) {
@@ -520,7 +611,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             uint32_t hv[2][4];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint32_t w0 = lds[2 * pair + k + 1][q], w1 = lds[2 * pair + k + 1][q + 1], w2 = lds[2 * pair + k + 1][q + 2];
+                const uint32_t *lr = &lds[2 * pair + k + 1][FT_XW - 1 + q];
+                const uint32_t w0 = lr[0], w1 = lr[1], w2 = lr[2];
                 hv[k][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
                 hv[k][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
                 hv[k][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
@@ -531,6 +623,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
                                                        hv[0][2] | (hv[1][2] << 16), hv[0][3] | (hv[1][3] << 16));
         }
     }
+#endif
     __syncthreads();
 
     /* Phase 2, queued pixels only: R = max over the 16 arcs of min9(v - p) and of min9(p - v) */
@@ -540,7 +633,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const int n = (FT_SKIP & 4) ? 0 : n_list;
     for (int e = threadIdx.x; e < n; e += FT_THREADS) {
         const int ly = (int)(list[e] >> 8) - 1, lx = (int)(list[e] & 0xFF) - 1;
-        const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + 4 + lx;
+        const uint8_t *c = tile8 + (ly + 4) * (FT_WORDS * 4) + FT_XB + lx;
         const int v = c[0];
         /* max over arcs of min9(v - p) = v - (min over arcs of max9(p)) and max over arcs of min9(p - v) =
          * (max over arcs of min9(p)) - v: the 16 differences are never formed */
@@ -563,7 +656,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         }
         const int R = imax(v - arc_hi, arc_lo - v);
         if (R > min_th) {
-            out8[(ly + 1) * (FT_WORDS * 4) + 4 + lx] = (uint8_t)(R - 1);
+            out8[(ly + 1) * (FT_OWORDS * 4) + 4 + lx] = (uint8_t)(R - 1);
             if ((unsigned)lx < SS_TILE_W && (unsigned)ly < SS_TILE_H2) corners[atomicAdd(&n_corner, 1)] = (uint16_t)((ly << 8) | lx);
         }
     }
@@ -580,7 +673,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         const uint32_t xi = xinf[lx], yi = yinf[ly];
         uint16_t code = 0xFFFFu;
         if ((xi & SS_CI_VALID) && (yi & SS_CI_VALID)) {
-            const uint8_t *c = out8 + (ly + 1) * (FT_WORDS * 4) + 4 + lx;
+            const uint8_t *c = out8 + (ly + 1) * (FT_OWORDS * 4) + 4 + lx;
             const int sc = c[0];
             const bool left_ok = !(xi & SS_CI_LOW), right_ok = !(xi & SS_CI_HIGH);
             const bool up_ok = !(yi & SS_CI_LOW), down_ok = !(yi & SS_CI_HIGH);
@@ -592,7 +685,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
                     if (dx == 0 && dy == 0) continue;
                     const bool ok = (dx < 0 ? left_ok : dx > 0 ? right_ok : true) &&
                                     (dy < 0 ? up_ok : dy > 0 ? down_ok : true);
-                    m = imax(m, ok ? (int)c[dy * (FT_WORDS * 4) + dx] : 0);
+                    m = imax(m, ok ? (int)c[dy * (FT_OWORDS * 4) + dx] : 0);
                 }
             if (sc > m) {
                 const int k = ((int)(yi & SS_CI_CELL) - row0) * 3 + ((int)(xi & SS_CI_CELL) - col0);
@@ -615,8 +708,15 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         for (int i = 0; i < 4; i++) {
             const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
             const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
+#if FT_BLUR_MFMA
+            /* the sums are stored less 32768 (int16): 256 * 32768 comes back with the rounding constant */
+            constexpr int RND = 32768 + 256 * 32768;
+            va[i] = (uint32_t)dot2_i16(p0, KA0, dot2_i16(p1, KA1, dot2_i16(p2, KA2, dot2_i16(p3, KA3, RND))));
+            vb[i] = (uint32_t)dot2_i16(p0, KB0, dot2_i16(p1, KB1, dot2_i16(p2, KB2, dot2_i16(p3, KB3, RND))));
+#else
             va[i] = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
             vb[i] = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
+#endif
         }
         /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24): three v_perm_b32 gather four of them */
         const uint32_t out_a = __builtin_amdgcn_perm(va[1], va[0], 0x0C0C0602u) | __builtin_amdgcn_perm(va[3], va[2], 0x06020C0Cu);
@@ -648,7 +748,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         for (int j = 0; j < SS_TS_CELLS - 1; j++) idx += j < k ? (int)(s_kcnt[j] & 0xFFFFu) : 0;
         const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
         if (idx < SS_TS_CAP)
-            tsurv[tslot * SS_TS_CAP + idx] = SS_PACK(x0 + lx - SS_MIN_BORDER, y0 + ly - SS_MIN_BORDER, out8[(ly + 1) * (FT_WORDS * 4) + 4 + lx]);
+            tsurv[tslot * SS_TS_CAP + idx] = SS_PACK(x0 + lx - SS_MIN_BORDER, y0 + ly - SS_MIN_BORDER, out8[(ly + 1) * (FT_OWORDS * 4) + 4 + lx]);
         else
             atomicExch(&state[(size_t)frame * SS_MAX_LEVELS_ + level].error, -5);
     }
@@ -1842,8 +1942,6 @@ __global__ __launch_bounds__(256) void k_match(const uint32_t *__restrict__ quer
 /* with the same key = distance << 16 | local row as k_match, and lanes l / l + 32 merge at the end. */
 /* Same grid contract, same partial / final outputs as k_match.                                      */
 /* ------------------------------------------------------------------------------------ */
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
 #define MM_ROW_BYTES 272
 #define MM_TILE 32
 /* NU = 32-query B tiles per wave.  1: 117 VGPRs, four waves per SIMD -- as fast alone on the 2000 x 2000 frames and 2 % more
