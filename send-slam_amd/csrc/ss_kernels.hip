@@ -168,26 +168,27 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 }
 
 /* LDS-staged, separable form of the same step for pyramid scale factors <= 1.4 (the source window of a 64x64
- * destination tile then fits 96 B x 80 rows).  cv::resize's 8-bit linear path is two passes with a rounding in between:
+ * destination tile then fits 112 B x 80 rows, from a 16-byte aligned column on).  cv::resize's 8-bit linear path is two passes with a rounding in between:
  * h = S[s0] * a0 + S[s1] * a1 per source row, then ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2 >> 2.  Every
  * source row serves two destination rows, so the horizontal sums are formed ONCE per source row (78 rows for 64
  * destination rows at 1.2) and kept in LDS as h >> 4 (16 bits):
  *   pass 1  thread = four destination columns x every 16th source row.  The <= 8 source bytes of the four columns are
  *           12 staged bytes funnelled to 8 (two v_alignbyte); one v_perm_b32 per column picks its two taps' bytes into
  *           16-bit halves and one v_dot2_u32_u16 multiplies them by (a0, a1): two instructions per sum, no byte loads,
- *           no per-tap address.  s1 = s0 + 1 wherever a1 != 0 (ss_geometry.cpp build_axis_table).
+ *           no per-tap address.  The taps are carried times 16, so h >> 4 is bytes 1-2 of the product sum and one
+ *           v_perm_b32 packs two of them for the store.  s1 = s0 + 1 wherever a1 != 0 (ss_geometry.cpp build_axis_table).
  *   pass 2  thread = four destination columns x four destination rows: two 8-byte LDS reads per row, products on the
  *           24-bit multiplier with SDWA half-word operands.
  * 15 VALU lane-operations per pixel against 26 for the one-pass form that formed every h twice. */
 #define RS_TILE_H 64
 #define RS_ROWS 80 /* 64 * 1.2 + 2 rounded up */
-#define RS_WORDS 24
+#define RS_WORDS 28 /* 112-byte source rows from a 16-byte aligned column on: 64 * 1.2 + 2 bytes + 15 of alignment */
 
 __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
                                                     const ss_rtab *__restrict__ rtab, int level,
                                                     const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
 {
-    __shared__ uint32_t lds[RS_ROWS + 1][RS_WORDS]; /* + 1: a funnel may read one dword past the last row's window */
+    __shared__ __attribute__((aligned(16))) uint32_t lds[RS_ROWS + 1][RS_WORDS]; /* + 1: a funnel may read one dword past the last row's window */
     __shared__ __attribute__((aligned(8))) uint16_t hbuf[RS_ROWS][SS_TILE_W];
     __shared__ ss_rtab yt[RS_TILE_H];
     const ss_level &D = g->lv[level];
@@ -205,25 +206,26 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 #pragma unroll
     for (int i = 0; i < 4; i++) rx[i] = rtab[D.xtab_off + x0 + 4 * tx + i];
     if (threadIdx.x < RS_TILE_H) yt[threadIdx.x] = rtab[D.ytab_off + imin(y0 + (int)threadIdx.x, D.h - 1)];
-    const int gx0 = (int)rtab[D.xtab_off + x0].s0 & ~3;      /* first source byte, dword aligned */
+    const int gx0 = (int)rtab[D.xtab_off + x0].s0 & ~15;     /* first source byte, 16-byte aligned (rows are: levels have a
+                                                              * 64-byte pitch, the caller's level 0 a 16-byte one) */
     const int gy0 = (int)rtab[D.ytab_off + imin(y0, D.h - 1)].s0;
     const int gy1 = (int)rtab[D.ytab_off + imin(y0 + RS_TILE_H - 1, D.h - 1)].s1; /* last source row used */
     {
-        /* all of a thread's loads first, then the LDS stores: one memory latency instead of one per round */
-        constexpr int ROUNDS = (RS_ROWS * RS_WORDS + 255) / 256;
-        uint32_t v[ROUNDS];
+        /* 16 bytes per load; all of a thread's loads first, then the LDS stores: one memory latency instead of one per round */
+        constexpr int VEC = RS_WORDS / 4, ROUNDS = (RS_ROWS * VEC + 255) / 256;
+        uint4 v[ROUNDS];
 #pragma unroll
         for (int it = 0; it < ROUNDS; it++) {
             const int idx = (int)threadIdx.x + 256 * it;
-            const int r = idx / RS_WORDS, c = idx - r * RS_WORDS;
-            const int gy = gy0 + r, gx = gx0 + 4 * c;
+            const int r = idx / VEC, c = idx - r * VEC;
+            const int gy = gy0 + r, gx = gx0 + 16 * c;
             /* rows and pitches are far below 2^24 and a level below 2^32 bytes: v_mad_u32_u24 instead of a 64-bit multiply */
-            v[it] = (idx < RS_ROWS * RS_WORDS && gy <= gy1 && gx < spitch) ? *(const uint32_t *)(src + (__umul24((uint32_t)gy, (uint32_t)spitch) + (uint32_t)gx)) : 0u;
+            v[it] = (idx < RS_ROWS * VEC && gy <= gy1 && gx < spitch) ? *(const uint4 *)(src + (__umul24((uint32_t)gy, (uint32_t)spitch) + (uint32_t)gx)) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < ROUNDS; it++) {
             const int idx = (int)threadIdx.x + 256 * it;
-            if (idx < RS_ROWS * RS_WORDS) (&lds[0][0])[idx] = v[it];
+            if (idx < RS_ROWS * VEC) ((uint4 *)&lds[0][0])[idx] = v[it];
         }
     }
     /* pass 1 constants: dword b of the window row holds the first column's s0; the funnel {B:A} = 8 bytes from byte
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
     for (int i = 0; i < 4; i++) {
         const uint32_t k = (uint32_t)((int)rx[i].s0 - (int)rx[0].s0);
         sel[i] = 0x0C000C00u | k | ((k + 1) << 16);
-        taps[i] = (uint32_t)(uint16_t)rx[i].a0 | ((uint32_t)(uint16_t)rx[i].a1 << 16);
+        taps[i] = ((uint32_t)(uint16_t)rx[i].a0 << 4) | ((uint32_t)(uint16_t)rx[i].a1 << 20); /* 16 x the 11-bit weights: <= 2^15 */
     }
     __syncthreads();
     const int n_rows = gy1 - gy0 + 1;
@@ -246,10 +248,10 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
         const uint32_t *w = &lds[r][bword];
         const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
         const uint32_t fa = __builtin_amdgcn_alignbyte(d1, d0, fsh), fb = __builtin_amdgcn_alignbyte(d2, d1, fsh);
-        uint32_t hs[4];
+        uint32_t hs[4]; /* 16 h < 2^24: h >> 4 is its bytes 1 and 2, and one v_perm_b32 packs two of them */
 #pragma unroll
-        for (int i = 0; i < 4; i++) hs[i] = dot2_u16(__builtin_amdgcn_perm(fb, fa, sel[i]), taps[i], 0u) >> 4; /* < 2^16 */
-        *(uint2 *)&hbuf[r][4 * tx] = make_uint2(hs[0] | (hs[1] << 16), hs[2] | (hs[3] << 16));
+        for (int i = 0; i < 4; i++) hs[i] = dot2_u16(__builtin_amdgcn_perm(fb, fa, sel[i]), taps[i], 0u);
+        *(uint2 *)&hbuf[r][4 * tx] = make_uint2(__builtin_amdgcn_perm(hs[1], hs[0], 0x06050201u), __builtin_amdgcn_perm(hs[3], hs[2], 0x06050201u));
     }
     __syncthreads();
     const int dx4 = x0 + 4 * tx;
@@ -2586,9 +2588,9 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
                 int level, int n_frames, const ss_lvl0 &l0)
 {
-    /* source window of a 64x64 tile: (64 * scale + 1 + 3 alignment) bytes x (64 * scale + 2) rows */
+    /* source window of a 64x64 tile: (64 * scale + 1 + 15 alignment) bytes x (64 * scale + 2) rows */
     const float sx = (float)hg.lv[level - 1].w / (float)hg.lv[level].w, sy = (float)hg.lv[level - 1].h / (float)hg.lv[level].h;
-    if (64.f * sx + 6.f <= 4.f * RS_WORDS && (float)RS_TILE_H * sy + 3.f <= (float)RS_ROWS) {
+    if (64.f * sx + 18.f <= 4.f * RS_WORDS && (float)RS_TILE_H * sy + 3.f <= (float)RS_ROWS) {
         dim3 grid(((hg.lv[level].w + SS_TILE_W - 1) / SS_TILE_W) * ((hg.lv[level].h + RS_TILE_H - 1) / RS_TILE_H), n_frames);
         hipLaunchKernelGGL(k_resize_lds, grid, dim3(256), 0, s, pyr, dg, rtab, level, l0.ptr, l0.pitch, l0.frame_stride);
     } else {
