@@ -599,12 +599,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         }
     }
 #else
-    /* K6a horizontal pass on the same staged tile: 7 taps = two v_dot4_u32_u8 on the byte
-     * window [x-3, x+4] */
+    /* K6a horizontal pass on the same staged tile.  The 7 taps of pixel i of a dword sit at bytes i + 1 .. i + 7 of the
+     * three aligned dwords around it: one v_dot4_u32_u8 per dword that holds any of them, against the taps shifted into
+     * place (zeros elsewhere) -- 2 + 3 + 3 + 2 products for four pixels, no byte funnels */
     if (!(FT_SKIP & 2)) {
-        constexpr uint32_t K_LO = SS_GAUSS_K0 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K2 << 16) | ((uint32_t)SS_GAUSS_K3 << 24);
-        constexpr uint32_t K_HI = SS_GAUSS_K2 | (SS_GAUSS_K1 << 8) | (SS_GAUSS_K0 << 16);
-        /* one item = four pixels of the two rows of a pair: 16 dot products, ONE 16-byte LDS store */
+        constexpr uint32_t K0 = SS_GAUSS_K0, K1 = SS_GAUSS_K1, K2 = SS_GAUSS_K2, K3 = SS_GAUSS_K3;
+        /* pixel 0: bytes 1-3 of w0, 0-3 of w1; pixel 1: 2-3, 0-3, 0; pixel 2: 3, 0-3, 0-1; pixel 3: 0-3, 0-2 */
+        constexpr uint32_t A0 = (K0 << 8) | (K1 << 16) | (K2 << 24), B0 = K3 | (K2 << 8) | (K1 << 16) | (K0 << 24);
+        constexpr uint32_t A1 = (K0 << 16) | (K1 << 24), B1 = K2 | (K3 << 8) | (K2 << 16) | (K1 << 24), C1 = K0;
+        constexpr uint32_t A2 = K0 << 24, B2 = K1 | (K2 << 8) | (K3 << 16) | (K2 << 24), C2 = K1 | (K0 << 8);
+        constexpr uint32_t B3 = K0 | (K1 << 8) | (K2 << 16) | (K3 << 24), C3 = K2 | (K1 << 8) | (K0 << 16);
+        /* one item = four pixels of the two rows of a pair: 20 dot products, ONE 16-byte LDS store */
 #pragma unroll
         for (int it = 0; it < ((FT_BLUR_ROWS / 2) * 16 + FT_THREADS - 1) / FT_THREADS; it++) {
             const int idx = (int)threadIdx.x + FT_THREADS * it;
@@ -615,10 +620,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             for (int k = 0; k < 2; k++) {
                 const uint32_t *lr = &lds[2 * pair + k + 1][FT_XW - 1 + q];
                 const uint32_t w0 = lr[0], w1 = lr[1], w2 = lr[2];
-                hv[k][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K_HI, 0, false), false);
-                hv[k][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K_HI, 0, false), false);
-                hv[k][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K_LO, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K_HI, 0, false), false);
-                hv[k][3] = __builtin_amdgcn_udot4(w1, K_LO, __builtin_amdgcn_udot4(w2, K_HI, 0, false), false);
+                hv[k][0] = __builtin_amdgcn_udot4(w0, A0, __builtin_amdgcn_udot4(w1, B0, 0, false), false);
+                hv[k][1] = __builtin_amdgcn_udot4(w0, A1, __builtin_amdgcn_udot4(w1, B1, __builtin_amdgcn_udot4(w2, C1, 0, false), false), false);
+                hv[k][2] = __builtin_amdgcn_udot4(w0, A2, __builtin_amdgcn_udot4(w1, B2, __builtin_amdgcn_udot4(w2, C2, 0, false), false), false);
+                hv[k][3] = __builtin_amdgcn_udot4(w1, B3, __builtin_amdgcn_udot4(w2, C3, 0, false), false);
             }
             /* sums stay below 2^16 (255 * 256) */
             *(uint4 *)&hpair[pair][4 * q] = make_uint4(hv[0][0] | (hv[1][0] << 16), hv[0][1] | (hv[1][1] << 16),
