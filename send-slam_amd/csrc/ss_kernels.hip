@@ -612,8 +612,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         /* one item = four pixels of the two rows of a pair: 20 dot products, ONE 16-byte LDS store */
 #pragma unroll
         for (int it = 0; it < ((FT_BLUR_ROWS / 2) * 16 + FT_THREADS - 1) / FT_THREADS; it++) {
-            const int idx = (int)threadIdx.x + FT_THREADS * it;
-            if (idx >= (FT_BLUR_ROWS / 2) * 16) break;
+            /* the leftovers of the second round go to the LAST wave: the first has the longest way to the barrier */
+            static_assert((FT_BLUR_ROWS / 2) * 16 <= 2 * FT_THREADS, "two rounds");
+            const int idx = it ? 2 * FT_THREADS - 1 - (int)threadIdx.x : (int)threadIdx.x;
+            if (idx >= (FT_BLUR_ROWS / 2) * 16) continue;
             const int pair = idx >> 4, q = idx & 15; /* blur rows 2 pair, 2 pair + 1 = staged rows + 1 */
             uint32_t hv[2][4];
 #pragma unroll
@@ -632,6 +634,45 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     }
 #endif
     __syncthreads();
+
+    /* K6a vertical pass, two output rows per thread (rows 2ty and 2ty+1 read the same four row
+     * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path.  The queue of phase 2 rarely reaches the upper half
+     * of the block (a wave per 64 entries): those waves run this pass while the lower half scores, and take the NMS
+     * afterwards, while the lower half runs this pass -- the block's critical path loses one of the two. */
+    auto blur_v = [&]() {
+        if (FT_SKIP & 16) return;
+        constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
+        constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
+        constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
+        constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
+        uint32_t va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
+            const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
+#if FT_BLUR_MFMA
+            /* the sums are stored less 32768 (int16): 256 * 32768 comes back with the rounding constant */
+            constexpr int RND = 32768 + 256 * 32768;
+            va[i] = (uint32_t)dot2_i16(p0, KA0, dot2_i16(p1, KA1, dot2_i16(p2, KA2, dot2_i16(p3, KA3, RND))));
+            vb[i] = (uint32_t)dot2_i16(p0, KB0, dot2_i16(p1, KB1, dot2_i16(p2, KB2, dot2_i16(p3, KB3, RND))));
+#else
+            va[i] = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
+            vb[i] = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
+#endif
+        }
+        /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24): three v_perm_b32 gather four of them */
+        const uint32_t out_a = __builtin_amdgcn_perm(va[1], va[0], 0x0C0C0602u) | __builtin_amdgcn_perm(va[3], va[2], 0x06020C0Cu);
+        const uint32_t out_b = __builtin_amdgcn_perm(vb[1], vb[0], 0x0C0C0602u) | __builtin_amdgcn_perm(vb[3], vb[2], 0x06020C0Cu);
+        const int ya = y0 + 2 * ty;
+        if (x0 + 4 * tx < pitch) {
+            /* 24-bit multiply + 32-bit offset (a level is far below 2^32 bytes) instead of a 64-bit v_mad_i64_i32 */
+            const uint32_t o = __umul24((uint32_t)ya, (uint32_t)pitch) + (uint32_t)(x0 + 4 * tx);
+            if (ya < h) *(uint32_t *)(blur + fb + o) = out_a;
+            if (ya + 1 < h) *(uint32_t *)(blur + fb + (o + (uint32_t)pitch)) = out_b;
+        }
+    };
+    const bool upper_half = threadIdx.x >= FT_THREADS / 2; /* wave-uniform */
+    if (upper_half) blur_v();
 
     /* Phase 2, queued pixels only: R = max over the 16 arcs of min9(v - p) and of min9(p - v) */
     constexpr int RDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
@@ -675,7 +716,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     const int nc = (FT_SKIP & 8) ? 0 : n_corner, ini_th = g->ini_th;
     const uint32_t tc = tr[9];
     const int col0 = (int)(tc & 0xFFFFu), row0 = (int)(tc >> 16);
-    for (int e = threadIdx.x; e < nc; e += FT_THREADS) {
+    for (int e = (int)((threadIdx.x + FT_THREADS / 2) % FT_THREADS); e < nc; e += FT_THREADS) { /* upper half first */
         const int ly = corners[e] >> 8, lx = corners[e] & 0xFF;
         const uint32_t xi = xinf[lx], yi = yinf[ly];
         uint16_t code = 0xFFFFu;
@@ -703,39 +744,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         list[e] = code; /* the queue of phase 1 is free again */
     }
 
-    /* K6a vertical pass, two output rows per thread (rows 2ty and 2ty+1 read the same four row
-     * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path */
-    if (!(FT_SKIP & 16)) {
-        constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
-        constexpr uint32_t KA2 = SS_GAUSS_K2 | (SS_GAUSS_K1 << 16), KA3 = SS_GAUSS_K0;
-        constexpr uint32_t KB0 = (uint32_t)SS_GAUSS_K0 << 16, KB1 = SS_GAUSS_K1 | (SS_GAUSS_K2 << 16);
-        constexpr uint32_t KB2 = SS_GAUSS_K3 | (SS_GAUSS_K2 << 16), KB3 = SS_GAUSS_K1 | (SS_GAUSS_K0 << 16);
-        uint32_t va[4], vb[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
-            const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
-#if FT_BLUR_MFMA
-            /* the sums are stored less 32768 (int16): 256 * 32768 comes back with the rounding constant */
-            constexpr int RND = 32768 + 256 * 32768;
-            va[i] = (uint32_t)dot2_i16(p0, KA0, dot2_i16(p1, KA1, dot2_i16(p2, KA2, dot2_i16(p3, KA3, RND))));
-            vb[i] = (uint32_t)dot2_i16(p0, KB0, dot2_i16(p1, KB1, dot2_i16(p2, KB2, dot2_i16(p3, KB3, RND))));
-#else
-            va[i] = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
-            vb[i] = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
-#endif
-        }
-        /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24): three v_perm_b32 gather four of them */
-        const uint32_t out_a = __builtin_amdgcn_perm(va[1], va[0], 0x0C0C0602u) | __builtin_amdgcn_perm(va[3], va[2], 0x06020C0Cu);
-        const uint32_t out_b = __builtin_amdgcn_perm(vb[1], vb[0], 0x0C0C0602u) | __builtin_amdgcn_perm(vb[3], vb[2], 0x06020C0Cu);
-        const int ya = y0 + 2 * ty;
-        if (x0 + 4 * tx < pitch) {
-            /* 24-bit multiply + 32-bit offset (a level is far below 2^32 bytes) instead of a 64-bit v_mad_i64_i32 */
-            const uint32_t o = __umul24((uint32_t)ya, (uint32_t)pitch) + (uint32_t)(x0 + 4 * tx);
-            if (ya < h) *(uint32_t *)(blur + fb + o) = out_a;
-            if (ya + 1 < h) *(uint32_t *)(blur + fb + (o + (uint32_t)pitch)) = out_b;
-        }
-    }
+    if (!upper_half) blur_v();
     if (score) {
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
