@@ -441,7 +441,7 @@ def bench_host_pipeline(binding, frames_sets, w, h, nf, B, local_rank, depth=4, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 600 for the metric workload, 20 for the others)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default 1000 for the metric workload: a timed region of about 0.6 s, 20 for the others)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=0, help="frames per step (default 64; stereo 16)")
     ap.add_argument("--width", type=int, default=1280)
@@ -471,7 +471,7 @@ def main():
         a.gpus = world
     w, h, nf = a.width, a.height, a.features
     B = a.batch or 64
-    steps = a.steps or 600
+    steps = a.steps or 1000
     n_ctx = max(1, a.contexts)
     n_sets = max(2, -(-(CACHE_BYTES + (64 << 20)) // (B * w * h)))  # rotating device batches exceed the Infinity Cache
     n_sets = -(-n_sets // n_ctx) * n_ctx if n_sets > n_ctx else n_sets  # every context then meets several sets
