@@ -14,11 +14,12 @@
  *   K4  k_quadtree      ORBextractor::DistributeOctTree, one 4-wave workgroup per (frame, level)
  *   --  k_slots         ORBextractor::operator() output order (lapping-area rule)
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
- *   K7  k_match_mfma / k_match / k_match_stream / k_match_merge*   Hamming best / second best + ratio test
+ *   K7  k_match_mfma_x / k_match_mfma / k_match / k_match_stream / k_match_merge*   Hamming best / second best + ratio test
  *
  * Integer / byte work throughout.  The one contraction on the path, the Hamming distance of K7, runs on
- * the matrix cores as an exact i8 dot product (k_match_mfma); nothing else is
- * reshaped into a GEMM.  Every kernel takes the batch slot in blockIdx.y or .z so one launch covers a
+ * the matrix cores as an exact +-1 dot product (FP4 operands in k_match_mfma_x, i8 in k_match_mfma; DESIGN.md
+ * section 7); nothing else is reshaped into a GEMM (a matrix-pipe form of the blur's horizontal pass exists as a
+ * measured-slower variant, FT_BLUR_MFMA).  Every kernel takes the batch slot in blockIdx.y or .z so one launch covers a
  * batch of frames.  Level 0 of the pyramid is read IN PLACE from the caller's buffer when that is a
  * 1-channel image with 16-byte aligned rows (lvl0 != NULL below); otherwise k_ingest writes it into the
  * pyramid block first.
@@ -282,8 +283,8 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
 /* pixel is a corner at threshold t iff R > t and its cv::cornerScore is R - 1 for every    */
 /* such t, so ONE map serves iniTh and minTh.  Stored: R - 1 if R > minTh else 0.           */
 /* 64x32 tile per 256-thread block.  The tile, a 1-px ring of neighbours (whose scores the  */
-/* NMS needs) and their 3-px FAST rings are staged in LDS as aligned dwords; the 7x7        */
-/* Gaussian (K6a) needs the same bytes, so it rides in the same kernel: one global read     */
+/* NMS needs) and their 3-px FAST rings are staged in LDS (96-byte rows, 16-byte loads); 7x7 */
+/* Gaussian (K6a) needs the same bytes, so it rides in the same kernel: one global read      */
 /* feeds all three.                                                                         */
 /* NMS (K3a) runs inside the FAST cell windows: cv::FAST is called per cell sub-image, so a */
 /* pixel competes only with neighbours of ITS window (FAST_t's ring buffers hold 0 outside  */
