@@ -85,6 +85,25 @@ def _noop(_):
     return 0
 
 
+def usable_cores():
+    """cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box
+    shows all of the host's cores but grants a share of them)"""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(frames, nf, budget_s=12.0):
     """Oracle timed on host cores BEFORE the GPU is touched (a process pool forks).
     Returns the JSON object and the per-frame oracle outputs for the parity check."""
@@ -104,7 +123,7 @@ def cpu_baseline(frames, nf, budget_s=12.0):
             break
     times.sort()
     median = times[len(times) // 2]  # the shim's median rule (orbslam3_mono_networked.cc:661)
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     all_cores = n_jobs = None
     if cores > 1:
         # >= 4 jobs per core, frames reused round-robin (the workers inherit them by fork: nothing is pickled in),
@@ -121,7 +140,7 @@ def cpu_baseline(frames, nf, budget_s=12.0):
            "sample": f"{len(times)} of the bench's own 1280x720 frames, extract + self-match, median per frame "
                      f"{median * 1e3:.1f} ms, 1 thread (oracle/orb_oracle.c, -O3)",
            "all_cores_value": None if all_cores is None else round(all_cores, 2), "all_cores": cores,
-           "all_cores_sample": None if n_jobs is None else f"{n_jobs} frame jobs over a warmed pool of {cores} processes, one frame per job"}
+           "all_cores_sample": None if n_jobs is None else f"{n_jobs} frame jobs over a warmed pool of {cores} processes (affinity mask {len(os.sched_getaffinity(0))}, cgroup quota applied), one frame per job"}
     return obj, outs
 
 
