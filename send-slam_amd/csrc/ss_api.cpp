@@ -49,6 +49,7 @@ struct ss_ctx {
     std::string err;
     bool calibrated = false;
     bool force_ingest = false; /* SENDSLAM_FORCE_INGEST=1: always copy level 0 into the pyramid block (tests) */
+    bool resize_pair[SS_MAX_LEVELS] = {}; /* levels l, l + 1 built by one k_resize_pair launch (checked on the tap tables) */
     int skip_after = 0, n_extracts = 0; /* SENDSLAM_SKIP_AFTER=k: the mask applies from the k-th batch of the context on, and the
                                 * per-level state of the batch before is kept (so that what follows a skipped stage still has work) */
     int skip_stages = 0;       /* SENDSLAM_SKIP_STAGES bit mask, timing experiments only (results invalid): 1 quadtree, 2 orient_describe,
@@ -227,6 +228,14 @@ int ensure_geometry(ss_ctx *c, int w, int h)
         if (g.lv[l].item_cap > 2048)
             return fail(c, SS_ERR_INVALID_ARG, "n_features too large: per-level quota exceeds 2032");
     c->hg = g;
+    {
+        /* SENDSLAM_RESIZE_PAIRS=1: two pyramid levels per launch (k_resize_pair: four launches instead of seven, bit-exact).
+         * Off by default: alone it takes the same 0.126 ms per 64 frames, with four batches in flight it costs 7.6 % frames/s
+         * (31 KB of LDS per block and 10 % more instructions for the overlapping windows) */
+        const char *e = getenv("SENDSLAM_RESIZE_PAIRS");
+        for (int l = 1; l + 1 < g.n_levels && e && atoi(e);)
+            if (ssk_resize_pair_fits(g, c->tabs.rtab.data(), l)) { c->resize_pair[l] = true; l += 2; } else l += 1;
+    }
     const size_t B = (size_t)c->params.max_batch;
     HIP_TRY(c, hipMalloc((void **)&c->dg, sizeof(ss_geom)));
     HIP_TRY(c, hipMemcpy(c->dg, &g, sizeof(ss_geom), hipMemcpyHostToDevice));
@@ -311,9 +320,16 @@ int run_extract(ss_ctx *c, const void *d_pix, int n, int channels, int64_t row_s
         stage_timer t(c, "ingest", n * level_px(g, 0) * (channels + 1));
         ssk_ingest(s, d_pix, channels, row_stride, frame_stride, c0, c1, c2, c->pyr, c->dg, g, n);
     }
-    for (int l = 1; l < g.n_levels && !(skip_mask & 4); l++) {
-        stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
-        ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n, l0);
+    for (int l = 1; l < g.n_levels && !(skip_mask & 4);) {
+        if (c->resize_pair[l]) { /* two pyramid steps, the middle level never read back */
+            stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l) + level_px(g, l + 1)));
+            ssk_resize_pair(s, c->pyr, c->dg, g, c->d_rtab, l, n, l0);
+            l += 2;
+        } else {
+            stage_timer t(c, "resize", n * (level_px(g, l - 1) + level_px(g, l)));
+            ssk_resize(s, c->pyr, c->dg, g, c->d_rtab, l, n, l0);
+            l += 1;
+        }
     }
     if (!(skip_mask & 8)) {
         /* algorithmic bytes: read the pyramid once, write the blurred pyramid (the score map and the

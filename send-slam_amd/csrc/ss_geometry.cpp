@@ -307,6 +307,9 @@ int ss_build_geometry(const ss_orb_params &p, int width, int height, ss_geom *g,
             build_axis_table(L.h, P.h, false, tabs->rtab, L.h);
         }
     }
+    /* the resize kernels read a whole 64-column tile's taps whatever the level's width: the last table must not end
+     * the allocation short of that */
+    for (int i = 0; i < 64 && !tabs->rtab.empty(); i++) tabs->rtab.push_back(tabs->rtab.back());
     g->block_bytes = off;
     g->n_cells = cell_base;
     g->cand_total = cand_base;

@@ -20,6 +20,11 @@ void ssk_ingest(hipStream_t s, const void *src, int channels, int64_t row_stride
                 int c0, int c1, int c2, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, int n_frames);
 void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab,
                 int level, int n_frames, const ss_lvl0 &l0);
+/* levels `level` and `level + 1` in one launch (k_resize_pair), where ssk_resize_pair_fits(host geometry, HOST tap tables)
+ * said so */
+bool ssk_resize_pair_fits(const ss_geom &hg, const ss_rtab *host_rtab, int level);
+void ssk_resize_pair(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab, int level,
+                     int n_frames, const ss_lvl0 &l0);
 /* K2 + K3a + K6a fused: FAST response map, in-window NMS into per-tile survivor sub-lists, blurred pyramid -- one
  * staged tile, no global atomics */
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,

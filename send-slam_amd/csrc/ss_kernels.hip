@@ -25,6 +25,7 @@
  * pyramid block first.
  * Float steps are single IEEE operations (-ffp-contract=off, ss_float_steps.h).
  */
+#include <algorithm>
 #include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -274,6 +275,140 @@ __global__ __launch_bounds__(256) void k_resize_lds(uint8_t *__restrict__ pyr, c
             out |= ((uint32_t)v & 0xFFu) << (8 * i);
         }
         *(uint32_t *)(base + D.off + (__umul24((uint32_t)dy, (uint32_t)D.pitch) + (uint32_t)dx4)) = out;
+    }
+}
+
+/* Two pyramid steps in one launch: a block builds a 48x64 tile of level l+1 AND, first, the part of level l it is
+ * resized from -- 64 columns x <= 80 rows, computed from level l-1 into LDS by the same two passes as k_resize_lds, never
+ * read back from memory.  Level l is still written (every block stores the columns / rows from its own window origin up to
+ * its right / lower neighbour's: each pixel by exactly one block), level l+1 reads level l's ROUNDED bytes from LDS, so
+ * both levels are bit for bit what two launches produce.  The windows overlap by 1-2 pixels: 14 % more pixels of level l
+ * are computed, and staging level l for the second step is gone; seven pyramid launches become four.
+ * The host launches this only for level pairs whose windows it has checked against the buffer sizes below, tile by tile
+ * (ssk_resize_pair_fits). */
+#define RP_TILE_W 48
+#define RP_A_ROWS 80                      /* rows of level l a block holds (= RS_ROWS: the second step's source window) */
+#define RP_S_ROWS 98                      /* rows of level l-1 staged for them: 80 * 1.2 + 2 */
+#define RP_B_WORDS 20                     /* pitch of the level-l window in LDS: 64 computed bytes + 16 a funnel may touch */
+
+__global__ __launch_bounds__(256) void k_resize_pair(uint8_t *__restrict__ pyr, const ss_geom *__restrict__ g,
+                                                     const ss_rtab *__restrict__ rtab, int level,
+                                                     const uint8_t *__restrict__ lvl0, int lvl0_pitch, int64_t lvl0_fs)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds_s[RP_S_ROWS + 1][RS_WORDS]; /* level l-1 window */
+    __shared__ __attribute__((aligned(8))) uint16_t hbuf[RP_S_ROWS][SS_TILE_W];      /* horizontal sums of either step */
+    __shared__ uint32_t lds_a[RP_A_ROWS + 1][RP_B_WORDS];                            /* level l window */
+    __shared__ ss_rtab yt_a[RP_A_ROWS], yt_b[RS_TILE_H];
+    const ss_level &S = g->lv[level - 1];
+    const ss_level &A = g->lv[level];
+    const ss_level &B = g->lv[level + 1];
+    const int tiles_x = (B.w + RP_TILE_W - 1) / RP_TILE_W, tiles_y = (B.h + RS_TILE_H - 1) / RS_TILE_H;
+    const int tile = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    const int x0 = tile_x * RP_TILE_W, y0 = tile_y * RS_TILE_H;
+    uint8_t *base = pyr + (size_t)blockIdx.y * g->block_bytes;
+    const bool inplace = level == 1 && lvl0 != nullptr; /* level 0 lives in the caller's buffer */
+    const uint8_t *src = inplace ? lvl0 + (int64_t)blockIdx.y * lvl0_fs : base + S.off;
+    const int spitch = inplace ? lvl0_pitch : S.pitch;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+
+    /* the level-l window: origin, what of it this block stores, how many rows it computes */
+    const int ax0 = (int)rtab[B.xtab_off + x0].s0 & ~3;
+    const int ay0 = (int)rtab[B.ytab_off + y0].s0;
+    const int ax_end = tile_x == tiles_x - 1 ? A.pitch : ((int)rtab[B.xtab_off + x0 + RP_TILE_W].s0 & ~3);
+    const int ay_end = tile_y == tiles_y - 1 ? A.h : (int)rtab[B.ytab_off + y0 + RS_TILE_H].s0;
+    const int ay_need = (int)rtab[B.ytab_off + imin(y0 + RS_TILE_H - 1, B.h - 1)].s1 + 1;
+    const int n_a = imax(ay_need, ay_end) - ay0; /* <= RP_A_ROWS (host check) */
+
+    /* step 1 taps: this thread's four columns of level l; row taps of the window to LDS */
+    ss_rtab rx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) rx[i] = rtab[A.xtab_off + ax0 + 4 * tx + i]; /* x tables are padded past w */
+    if (threadIdx.x < RP_A_ROWS) yt_a[threadIdx.x] = rtab[A.ytab_off + imin(ay0 + (int)threadIdx.x, A.h - 1)];
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + RS_TILE_H) yt_b[threadIdx.x - 128] = rtab[B.ytab_off + imin(y0 + (int)threadIdx.x - 128, B.h - 1)];
+    const int gx0 = (int)rtab[A.xtab_off + ax0].s0 & ~15;
+    const int gy0 = (int)rtab[A.ytab_off + ay0].s0;
+    const int gy1 = (int)rtab[A.ytab_off + imin(ay0 + n_a - 1, A.h - 1)].s1; /* <= gy0 + RP_S_ROWS - 1 (host check) */
+    {
+        constexpr int VEC = RS_WORDS / 4, ROUNDS = (RP_S_ROWS * VEC + 255) / 256;
+        uint4 v[ROUNDS];
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            const int r = idx / VEC, c = idx - r * VEC;
+            const int gy = gy0 + r, gx = gx0 + 16 * c;
+            v[it] = (idx < RP_S_ROWS * VEC && gy <= gy1 && gx < spitch) ? *(const uint4 *)(src + (__umul24((uint32_t)gy, (uint32_t)spitch) + (uint32_t)gx)) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            if (idx < RP_S_ROWS * VEC) ((uint4 *)&lds_s[0][0])[idx] = v[it];
+        }
+    }
+    /* horizontal pass of one step: source rows [0, n_rows) of a window with `pitch` dwords per row whose byte 0 is source
+     * column `origin`; four destination columns per thread with taps t[4] (k_resize_lds pass 1) */
+    auto h_pass = [&](const uint32_t *win, int pitch, int origin, const ss_rtab (&t)[4], int n_rows, int max_rounds) {
+        const int o0 = (int)t[0].s0 - origin, bword = o0 >> 2;
+        const uint32_t fsh = (uint32_t)o0 & 3u;
+        uint32_t sel[4], taps[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t k = (uint32_t)((int)t[i].s0 - (int)t[0].s0);
+            sel[i] = 0x0C000C00u | k | ((k + 1) << 16);
+            taps[i] = ((uint32_t)(uint16_t)t[i].a0 << 4) | ((uint32_t)(uint16_t)t[i].a1 << 20);
+        }
+        for (int rr = 0; rr < max_rounds; rr++) {
+            const int r = ty + 16 * rr;
+            if (r >= n_rows) break;
+            const uint32_t *w = win + r * pitch + bword;
+            const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+            const uint32_t fa = __builtin_amdgcn_alignbyte(d1, d0, fsh), fb = __builtin_amdgcn_alignbyte(d2, d1, fsh);
+            uint32_t hs[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) hs[i] = dot2_u16(__builtin_amdgcn_perm(fb, fa, sel[i]), taps[i], 0u);
+            *(uint2 *)&hbuf[r][4 * tx] = make_uint2(__builtin_amdgcn_perm(hs[1], hs[0], 0x06050201u), __builtin_amdgcn_perm(hs[3], hs[2], 0x06050201u));
+        }
+    };
+    /* vertical pass: four pixels of destination row `ry` from the sums of its two source rows (k_resize_lds pass 2) */
+    auto v_dword = [&](const ss_rtab ry, int row0) -> uint32_t {
+        const uint2 h0 = *(const uint2 *)&hbuf[ry.s0 - row0][4 * tx], h1 = *(const uint2 *)&hbuf[ry.s1 - row0][4 * tx];
+        const int b0 = ry.a0, b1 = ry.a1;
+        const uint32_t p0[4] = {h0.x & 0xFFFFu, h0.x >> 16, h0.y & 0xFFFFu, h0.y >> 16};
+        const uint32_t p1[4] = {h1.x & 0xFFFFu, h1.x >> 16, h1.y & 0xFFFFu, h1.y >> 16};
+        uint32_t out = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int v = ((__mul24(b0, (int)p0[i]) >> 16) + (__mul24(b1, (int)p1[i]) >> 16) + 2) >> 2;
+            out |= ((uint32_t)v & 0xFFu) << (8 * i);
+        }
+        return out;
+    };
+    __syncthreads();
+    h_pass(&lds_s[0][0], RS_WORDS, gx0, rx, gy1 - gy0 + 1, (RP_S_ROWS + 15) / 16);
+    __syncthreads();
+    {
+        const int dx4 = ax0 + 4 * tx;
+        const bool store_col = dx4 < ax_end && dx4 < A.w;
+        for (int rr = 0; rr < RP_A_ROWS / 16; rr++) {
+            const int ly = ty + 16 * rr, dy = ay0 + ly;
+            if (ly >= n_a) break;
+            const uint32_t out = v_dword(yt_a[ly], gy0);
+            lds_a[ly][tx] = out;
+            if (store_col && dy < ay_end) *(uint32_t *)(base + A.off + (__umul24((uint32_t)dy, (uint32_t)A.pitch) + (uint32_t)dx4)) = out;
+        }
+    }
+    /* step 2: the tile of level l+1 from the window just built */
+#pragma unroll
+    for (int i = 0; i < 4; i++) rx[i] = rtab[B.xtab_off + x0 + 4 * tx + i];
+    __syncthreads();
+    h_pass(&lds_a[0][0], RP_B_WORDS, ax0, rx, n_a, RP_A_ROWS / 16);
+    __syncthreads();
+    const int dx4 = x0 + 4 * tx;
+    if (4 * tx >= RP_TILE_W || dx4 >= B.w) return;
+    for (int rr = 0; rr < RS_TILE_H / 16; rr++) {
+        const int ly = ty + 16 * rr, dy = y0 + ly;
+        if (dy >= B.h) break;
+        *(uint32_t *)(base + B.off + (__umul24((uint32_t)dy, (uint32_t)B.pitch) + (uint32_t)dx4)) = v_dword(yt_b[ly], ay0);
     }
 }
 
@@ -2612,6 +2747,70 @@ void ssk_resize(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &h
         dim3 grid((hg.lv[level].w + 255) / 256, (hg.lv[level].h + 3) / 4, n_frames);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, pyr, dg, rtab, level, l0.ptr, l0.pitch, l0.frame_stride);
     }
+}
+
+/* May levels `level` and `level + 1` be built by one k_resize_pair launch?  Checked on the real tap tables, tile by
+ * tile: every window the kernel forms must fit the buffers it is compiled with. */
+bool ssk_resize_pair_fits(const ss_geom &hg, const ss_rtab *t, int level)
+{
+    if (level < 1 || level + 1 >= hg.n_levels) return false;
+    const ss_level &S = hg.lv[level - 1], &A = hg.lv[level], &B = hg.lv[level + 1];
+    if (A.w < 64 || A.h < 8 || B.w < 8 || B.h < 8) return false;
+    const int tiles_x = (B.w + RP_TILE_W - 1) / RP_TILE_W, tiles_y = (B.h + RS_TILE_H - 1) / RS_TILE_H;
+    for (int ty = 0; ty < tiles_y; ty++) {
+        const int y0 = ty * RS_TILE_H;
+        const int ay0 = t[B.ytab_off + y0].s0;
+        const int ay_end = ty == tiles_y - 1 ? A.h : (int)t[B.ytab_off + y0 + RS_TILE_H].s0;
+        const int ay_need = (int)t[B.ytab_off + std::min(y0 + RS_TILE_H - 1, B.h - 1)].s1 + 1;
+        const int n_a = std::max(ay_need, ay_end) - ay0;
+        if (n_a < 1 || n_a > RP_A_ROWS || ay_end < ay0) return false;
+        const int gy0 = t[A.ytab_off + ay0].s0, gy1 = t[A.ytab_off + std::min(ay0 + n_a - 1, A.h - 1)].s1;
+        if (gy1 - gy0 + 1 > RP_S_ROWS || gy1 >= S.h) return false;
+        /* every row tap of the window must lie inside it */
+        for (int r = 0; r < n_a; r++) {
+            const ss_rtab &e = t[A.ytab_off + std::min(ay0 + r, A.h - 1)];
+            if (e.s0 < gy0 || e.s1 > gy1) return false;
+        }
+        for (int r = 0; r < RS_TILE_H && y0 + r < B.h; r++) {
+            const ss_rtab &e = t[B.ytab_off + y0 + r];
+            if (e.s0 < ay0 || e.s1 >= ay0 + n_a) return false;
+        }
+    }
+    for (int tx = 0; tx < tiles_x; tx++) {
+        const int x0 = tx * RP_TILE_W;
+        const int ax0 = (int)t[B.xtab_off + x0].s0 & ~3;
+        const int ax_end = tx == tiles_x - 1 ? A.pitch : ((int)t[B.xtab_off + x0 + RP_TILE_W].s0 & ~3);
+        /* stored columns: [ax0, ax_end) below A.w must be among the 64 computed ones */
+        if (std::min(ax_end, (A.w + 3) & ~3) > ax0 + 64 || ax_end < ax0) return false;
+        const int gx0 = (int)t[A.xtab_off + ax0].s0 & ~15;
+        for (int c = 0; c < 64; c += 4) {
+            /* a thread's funnel: 12 bytes from the dword of its first tap; its taps within 8 bytes of it */
+            const ss_rtab &f = t[A.xtab_off + ax0 + c];
+            if (((f.s0 - gx0) >> 2) * 4 + 12 > 4 * RS_WORDS) return false;
+            for (int i = 0; i < 4; i++) {
+                const ss_rtab &e = t[A.xtab_off + ax0 + c + i];
+                if (e.s0 - f.s0 > 6 || (e.a1 != 0 && e.s1 != e.s0 + 1)) return false;
+            }
+        }
+        for (int c = 0; c < RP_TILE_W && x0 + c < B.w; c += 4) {
+            const ss_rtab &f = t[B.xtab_off + x0 + c];
+            if (f.s0 < ax0 || ((f.s0 - ax0) >> 2) * 4 + 12 > 4 * RP_B_WORDS) return false;
+            for (int i = 0; i < 4; i++) {
+                const ss_rtab &e = t[B.xtab_off + x0 + c + i];
+                if (e.s0 - f.s0 > 6 || (e.a1 != 0 && e.s1 != e.s0 + 1)) return false;
+                if (x0 + c + i < B.w && (int)e.s1 >= ax0 + 64) return false; /* a tap outside the computed columns */
+            }
+        }
+    }
+    return true;
+}
+
+void ssk_resize_pair(hipStream_t s, uint8_t *pyr, const ss_geom *dg, const ss_geom &hg, const ss_rtab *rtab, int level,
+                     int n_frames, const ss_lvl0 &l0)
+{
+    const ss_level &B = hg.lv[level + 1];
+    dim3 grid(((B.w + RP_TILE_W - 1) / RP_TILE_W) * ((B.h + RS_TILE_H - 1) / RS_TILE_H), n_frames);
+    hipLaunchKernelGGL(k_resize_pair, grid, dim3(256), 0, s, pyr, dg, rtab, level, l0.ptr, l0.pitch, l0.frame_stride);
 }
 
 void ssk_fast_blur_nms(hipStream_t s, const uint8_t *pyr, uint8_t *score, uint8_t *blur, const ss_geom *dg, const ss_geom &hg,

@@ -165,6 +165,35 @@ def test_level0_in_place_equals_ingest_copy(oracle, w, h, nf, monkeypatch):
             assert out[force][b][0].tobytes() == okps.tobytes() and np.array_equal(out[force][b][1], odesc)
 
 
+@pytest.mark.parametrize("w,h,nf,scale,nl", [(1280, 720, 2000, 1.2, 8), (640, 480, 1250, 1.2, 8), (811, 523, 700, 1.15, 7),
+                                             (336, 250, 300, 1.2, 5), (1000, 700, 900, 1.1, 6)])
+def test_two_pyramid_levels_per_launch_equal_one(oracle, w, h, nf, scale, nl, monkeypatch):
+    """SENDSLAM_RESIZE_PAIRS=1 (read at ss_create): k_resize_pair builds levels l and l + 1 in one launch, level l + 1 from
+    the bytes of level l it has just computed in LDS.  Every level, the keypoints and the descriptors equal the one-launch-
+    per-level path and the oracle, bit for bit (in-place level 0 and the ingest copy both)."""
+    import torch
+    frames = np.stack([synth.frame(900 + i, w, h) for i in range(2)])
+    d = torch.from_numpy(frames).to("cuda:0")
+    p = oracle.default_params(n_features=nf, scale_factor=scale, n_levels=nl)
+    g = oracle.geometry(p, w, h)
+    out = {}
+    for pairs, ingest in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("SENDSLAM_RESIZE_PAIRS", pairs)
+        monkeypatch.setenv("SENDSLAM_FORCE_INGEST", ingest)
+        with binding.OrbContext(0, n_features=nf, max_batch=2, scale_factor=scale, n_levels=nl) as ctx:
+            ctx.extract_batch_device(d.data_ptr(), 2, w, h)
+            ctx.synchronize()
+            levels = [ctx.debug_fetch(0, 1, l, (g.h[l], g.w[l])).copy() for l in range(1, nl)]
+            out[pairs + ingest] = ([ctx.fetch_frame(b) for b in range(2)], levels)
+    for key in ("10", "11"):
+        for l in range(nl - 1):
+            assert np.array_equal(out[key][1][l], out["00"][1][l]), (key, "level", l + 1)
+    for b in range(2):
+        okps, odesc, _ = oracle.extract(frames[b], p)
+        for key in out:
+            assert out[key][0][b][0].tobytes() == okps.tobytes() and np.array_equal(out[key][0][b][1], odesc), key
+
+
 def test_steer_fma_both_forms_vs_oracle(oracle):
     """The rBRIEF tap coordinates as written (0) and with GCC's FMA contraction (1): each device form equals the
     oracle's form of the same name; on this frame the two differ in one descriptor bit (keypoint 1341), which is the
