@@ -77,6 +77,18 @@ __device__ __forceinline__ int wave_sum(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+/* inclusive prefix sum over the 64 lanes: four row shifts inside the 16-lane rows, two row broadcasts across them */
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); /* row_bcast15 -> rows 1, 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); /* row_bcast31 -> rows 2, 3 */
+    return v;
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int dot2_i16(uint32_t a, uint32_t b, int c)
@@ -859,18 +871,15 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         if ((xi & SS_CI_VALID) && (yi & SS_CI_VALID)) {
             const uint8_t *c = out8 + (ly + 1) * (FT_OWORDS * 4) + 4 + lx;
             const int sc = c[0];
-            const bool left_ok = !(xi & SS_CI_LOW), right_ok = !(xi & SS_CI_HIGH);
-            const bool up_ok = !(yi & SS_CI_LOW), down_ok = !(yi & SS_CI_HIGH);
-            int m = 0;
-#pragma unroll
-            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                for (int dx = -1; dx <= 1; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const bool ok = (dx < 0 ? left_ok : dx > 0 ? right_ok : true) &&
-                                    (dy < 0 ? up_ok : dy > 0 ? down_ok : true);
-                    m = imax(m, ok ? (int)c[dy * (FT_OWORDS * 4) + dx] : 0);
-                }
+            /* all eight neighbours are read at once (the score tile has a ring, so every address is valid) and the ones
+             * outside the pixel's cell window are masked to 0 -- as conditional reads they were eight dependent LDS round
+             * trips on the critical path of the one wave that runs the NMS */
+            constexpr int P = FT_OWORDS * 4;
+            const int lm = (xi & SS_CI_LOW) ? 0 : 0xFF, rm = (xi & SS_CI_HIGH) ? 0 : 0xFF;
+            const int um = (yi & SS_CI_LOW) ? 0 : 0xFF, dm = (yi & SS_CI_HIGH) ? 0 : 0xFF;
+            const int n00 = c[-P - 1], n01 = c[-P], n02 = c[-P + 1], n10 = c[-1], n12 = c[1], n20 = c[P - 1], n21 = c[P], n22 = c[P + 1];
+            const int m = max3(max3(n00 & (um & lm), n01 & um, n02 & (um & rm)), max3(n10 & lm, n12 & rm, n20 & (dm & lm)),
+                               imax(n21 & dm, n22 & (dm & rm)));
             if (sc > m) {
                 const int k = ((int)(yi & SS_CI_CELL) - row0) * 3 + ((int)(xi & SS_CI_CELL) - col0);
                 const uint32_t old = atomicAdd(&s_kcnt[k], 1u | (sc >= ini_th ? 0x10000u : 0u));
@@ -944,13 +953,17 @@ __global__ __launch_bounds__(256) void k_bucket_gather(const ss_geom *__restrict
         ini = (int)(word >> 16);
         src = tsurv + tslot * SS_TS_CAP + pre;
     }
-    int incl = cnt, ini_sum = ini;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const int v = __shfl_up(incl, o, 16), w = __shfl_up(ini_sum, o, 16);
-        if (u >= o) { incl += v; ini_sum += w; }
-    }
-    const int total = __shfl(incl, 15, 16), total_ini = __shfl(ini_sum, 15, 16);
+    /* inclusive scan over the cell's 16 lanes = one DPP row: both counts in one word (each < 2^16), four row shifts (a
+     * lane whose source is left of the row keeps the 0 of `old`); lane 0 of the row reads the total from lane 15 by a row
+     * mirror.  (__shfl_up is ds_bpermute_b32, an LDS round trip per step.) */
+    int both = cnt | (ini << 16);
+    both += __builtin_amdgcn_update_dpp(0, both, 0x111, 0xF, 0xF, false); /* row_shr:1 */
+    both += __builtin_amdgcn_update_dpp(0, both, 0x112, 0xF, 0xF, false); /* row_shr:2 */
+    both += __builtin_amdgcn_update_dpp(0, both, 0x114, 0xF, 0xF, false); /* row_shr:4 */
+    both += __builtin_amdgcn_update_dpp(0, both, 0x118, 0xF, 0xF, false); /* row_shr:8 */
+    const int incl = both & 0xFFFF;
+    const int totals = __builtin_amdgcn_update_dpp(0, both, 0x140, 0xF, 0xF, false); /* row_mirror: lane 0 <- lane 15 */
+    const int total = totals & 0xFFFF, total_ini = (int)((uint32_t)totals >> 16);
     if (!live) return;
     uint32_t *bk = bucket + (size_t)frame * g->bucket_total + L.bucket_base + (size_t)(cell - L.cell_base) * L.bucket_cap;
     const int pos = incl - cnt;
@@ -1000,12 +1013,7 @@ __global__ __launch_bounds__(256) void k_cells_emit(const uint32_t *__restrict__
     const int before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     if (tid < WAVE) {
         const uint32_t word = s_cnt[tid];
-        int ia = imin((int)(word & 0xFFFFu), L.bucket_cap), io = cell_count_of(word);
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const int va = __shfl_up(ia, o, WAVE), vo = __shfl_up(io, o, WAVE);
-            if (lane >= o) { ia += va; io += vo; }
-        }
+        const int ia = wave_scan_incl(imin((int)(word & 0xFFFFu), L.bucket_cap)), io = wave_scan_incl(cell_count_of(word));
         s_all[tid + 1] = ia;
         s_out[tid + 1] = before + io;
         if (tid == 0) { s_all[0] = 0; s_out[0] = before; }
