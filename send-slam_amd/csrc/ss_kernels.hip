@@ -1270,7 +1270,10 @@ __device__ __forceinline__ void sort_final_rank(const uint64_t *a, uint64_t *tmp
 #endif
 
 struct qt_ctx {
-    uint32_t *buf[2];
+    /* the ping-pong record buffers as base + b * distance: an array indexed by a node's buffer bit (and a select between two
+     * members just the same) made the compiler keep the whole struct in scratch memory, a memory round trip per use */
+    uint32_t *buf0;
+    int64_t buf_step; /* bytes from buffer 0 to buffer 1 */
     ss_qnode *nodes;      /* global table */
     ss_qnode *lds_nodes;  /* LDS cache for indices < QT_LDS_NODES */
     int node_cap;
@@ -1283,10 +1286,15 @@ __device__ __forceinline__ ss_qnode *qt_node(const qt_ctx &q, int idx)
 {
     return idx < QT_LDS_NODES ? q.lds_nodes + idx : q.nodes + idx;
 }
+__device__ __forceinline__ uint32_t *qt_buf(const qt_ctx &q, int b) { return (uint32_t *)((char *)q.buf0 + (int64_t)b * q.buf_step); }
 /* stores with the address space spelled out: through generic pointers they would be FLAT instructions, which
  * count against the LDS counter too and would make lds_barrier() wait for global memory */
 typedef __attribute__((address_space(1))) uint32_t qt_gu32;
 typedef __attribute__((address_space(3))) uint32_t qt_lu32;
+/* ... and loads: a FLAT load (generic pointer: "LDS or global?") counts against the LDS counter as well, so the
+ * s_waitcnt lgkmcnt(0) of lds_barrier() waited for every record / node load in flight, the prefetched ones included */
+typedef const __attribute__((address_space(1))) uint32_t qt_cgu32;
+typedef const __attribute__((address_space(3))) uint32_t qt_clu32;
 static_assert(sizeof(ss_qnode) == 20, "ss_qnode is five dwords");
 __device__ __forceinline__ void qt_store_node(const qt_ctx &q, int idx, const ss_qnode &n)
 {
@@ -1301,6 +1309,23 @@ __device__ __forceinline__ void qt_store_node(const qt_ctx &q, int idx, const ss
 #pragma unroll
         for (int i = 0; i < 5; i++) p[i] = w[i];
     }
+}
+/* node record by a wave-uniform index: ds_read or global_load, never flat */
+__device__ __forceinline__ ss_qnode qt_load_node(const qt_ctx &q, int idx)
+{
+    uint32_t w[5];
+    if (idx < QT_LDS_NODES) {
+        qt_clu32 *p = (qt_clu32 *)(const uint32_t *)(q.lds_nodes + idx);
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = p[i];
+    } else {
+        qt_cgu32 *p = (qt_cgu32 *)(const uint32_t *)(q.nodes + idx);
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = p[i];
+    }
+    ss_qnode n;
+    __builtin_memcpy(&n, w, sizeof(w));
+    return n;
 }
 __device__ __forceinline__ void qt_store_flags(const qt_ctx &q, int idx, int flags)
 {
@@ -1327,38 +1352,63 @@ struct qt_div {
     int q0;
 };
 
-__device__ __forceinline__ void qt_count(const qt_ctx &q, int idx, qt_div &d, int c[4])
+/* what a division starts from: the node record and the first 64 records of its segment -- two DEPENDENT memory round trips
+ * (most node records live in global memory).  The nodes of a sweep's list are final when the sweep starts, so a wave
+ * fetches the node record two steps ahead of the step that divides the node and its records one step ahead: neither
+ * latency is left in a step's dependency chain. */
+struct qt_pre {
+    int idx;
+    ss_qnode nd;
+    uint32_t rec;
+};
+__device__ __forceinline__ void qt_fetch_node(const qt_ctx &q, int idx, qt_pre &p)
 {
-    const ss_qnode nd = *qt_node(q, idx);
+    p.idx = idx;
+    p.nd = qt_load_node(q, idx);
+}
+__device__ __forceinline__ void qt_fetch_records(const qt_ctx &q, qt_pre &p)
+{
+    const int b = (rfl(p.nd.flags) >> 2) & 1;
+    p.rec = lane_id() < rfl(p.nd.cnt) ? ((qt_cgu32 *)qt_buf(q, b))[rfl(p.nd.beg) + lane_id()] : 0u;
+}
+
+__device__ __forceinline__ void qt_count(const qt_ctx &q, const qt_pre &p, qt_div &d, int c[4])
+{
+    const ss_qnode &nd = p.nd;
     d.x0 = rfl(nd.x0); d.x1 = rfl(nd.x1); d.y0 = rfl(nd.y0); d.y1 = rfl(nd.y1);
     d.beg = rfl(nd.beg); d.cnt = rfl(nd.cnt); d.flags = rfl(nd.flags);
     d.b = (d.flags >> 2) & 1;
     d.xm = d.x0 + ((d.x1 - d.x0 + 1) >> 1); /* ceil((float)(UR.x-UL.x)/2) */
     d.ym = d.y0 + ((d.y1 - d.y0 + 1) >> 1);
-    const uint32_t *src = q.buf[d.b] + d.beg;
+    qt_cgu32 *src = (qt_cgu32 *)(qt_buf(q, d.b) + d.beg);
     const int lane = lane_id();
-    c[0] = c[1] = c[2] = c[3] = 0;
-    d.rec0 = 0;
-    d.q0 = 4;
-    for (int base = 0; base < d.cnt; base += WAVE) {
-        const int i = base + lane;
-        uint32_t rec = 0;
-        int quad = 4;
-        if (i < d.cnt) {
-            rec = src[i];
-            quad = (SS_PX(rec) >= d.xm ? 1 : 0) | (SS_PY(rec) >= d.ym ? 2 : 0);
-        }
-        if (base == 0) { d.rec0 = rec; d.q0 = quad; }
+    d.rec0 = p.rec;
+    d.q0 = lane < d.cnt ? (SS_PX(p.rec) >= d.xm ? 1 : 0) | (SS_PY(p.rec) >= d.ym ? 2 : 0) : 4;
 #pragma unroll
-        for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(quad == k));
+    for (int k = 0; k < 4; k++) c[k] = __popcll(__ballot(d.q0 == k));
+    /* a large node (the first passes): four chunks of 64 per round, their loads in flight together */
+    for (int base = WAVE; base < d.cnt; base += 4 * WAVE) {
+        uint32_t rec[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * WAVE + lane;
+            rec[u] = i < d.cnt ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * WAVE + lane;
+            const int quad = i < d.cnt ? (SS_PX(rec[u]) >= d.xm ? 1 : 0) | (SS_PY(rec[u]) >= d.ym ? 2 : 0) : 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] += __popcll(__ballot(quad == k));
+        }
     }
 }
 
 /* children get node indices first_child, first_child+1, ... in n1..n4 order (empty ones skipped) */
 __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_div &d, const int c[4], int first_child)
 {
-    const uint32_t *src = q.buf[d.b] + d.beg;
-    qt_gu32 *dst = (qt_gu32 *)(q.buf[d.b ^ 1] + d.beg); /* global_store, not flat_store (lds_barrier) */
+    qt_cgu32 *src = (qt_cgu32 *)(qt_buf(q, d.b) + d.beg);
+    qt_gu32 *dst = (qt_gu32 *)(qt_buf(q, d.b ^ 1) + d.beg); /* global_store, not flat_store (lds_barrier) */
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
     int run[4];
@@ -1367,23 +1417,27 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
     run[2] = c[0] + c[1];
     run[3] = c[0] + c[1] + c[2];
     const int o[4] = {run[0], run[1], run[2], run[3]};
-    for (int base = 0; base < d.cnt; base += WAVE) {
-        const int i = base + lane;
-        uint32_t rec = d.rec0;
-        int quad = d.q0;
-        if (base != 0) {
-            rec = 0;
-            quad = 4;
-            if (i < d.cnt) {
-                rec = src[i];
-                quad = (SS_PX(rec) >= d.xm ? 1 : 0) | (SS_PY(rec) >= d.ym ? 2 : 0);
-            }
-        }
+    auto place = [&](uint32_t rec, int quad) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint64_t m = __ballot(quad == k);
             if (quad == k) dst[run[k] + __popcll(m & lt)] = rec;
             run[k] += __popcll(m);
+        }
+    };
+    place(d.rec0, d.q0);
+    for (int base = WAVE; base < d.cnt; base += 4 * WAVE) {
+        uint32_t rec[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * WAVE + lane;
+            rec[u] = i < d.cnt ? src[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (base + u * WAVE >= d.cnt) break;
+            const int i = base + u * WAVE + lane;
+            place(rec[u], i < d.cnt ? (SS_PX(rec[u]) >= d.xm ? 1 : 0) | (SS_PY(rec[u]) >= d.ym ? 2 : 0) : 4);
         }
     }
     const int rx0[4] = {d.x0, d.xm, d.x0, d.xm}, rx1[4] = {d.xm, d.x1, d.xm, d.x1};
@@ -1441,8 +1495,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
     const int N = L.quota;
     const uint32_t *in = cand + (size_t)frame * g->cand_total + L.cand_base;
     qt_ctx q;
-    q.buf[0] = qbuf0 + (size_t)frame * g->cand_total + L.cand_base;
-    q.buf[1] = qbuf1 + (size_t)frame * g->cand_total + L.cand_base;
+    q.buf0 = qbuf0 + (size_t)frame * g->cand_total + L.cand_base;
+    q.buf_step = (int64_t)((intptr_t)qbuf1 - (intptr_t)qbuf0);
     q.nodes = nodes_all + (size_t)frame * g->node_total + L.node_base;
     q.lds_nodes = lds_nodes;
     q.node_cap = L.node_cap;
@@ -1466,17 +1520,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
         int root_beg = 0;
         for (int r = 0; r < n_ini; r++) {
             int cnt_r = 0;
-            for (int base = 0; base < n_cand; base += WAVE) {
-                const int i = base + lane;
-                bool mine = false;
-                uint32_t rec = 0;
-                if (i < n_cand) {
-                    rec = in[i];
-                    mine = (int)((float)SS_PX(rec) / hx) == r;
+            for (int base = 0; base < n_cand; base += 4 * WAVE) { /* four chunks per round: their loads in flight together */
+                uint32_t rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = base + u * WAVE + lane;
+                    rec[u] = i < n_cand ? in[i] : 0u;
                 }
-                const uint64_t m = __ballot(mine);
-                if (mine) q.buf[0][root_beg + cnt_r + __popcll(m & lt)] = rec;
-                cnt_r += __popcll(m);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = base + u * WAVE + lane;
+                    const bool mine = i < n_cand && (int)((float)SS_PX(rec[u]) / hx) == r;
+                    const uint64_t m = __ballot(mine);
+                    if (mine) q.buf0[root_beg + cnt_r + __popcll(m & lt)] = rec[u];
+                    cnt_r += __popcll(m);
+                }
             }
             ss_qnode nd;
             nd.x0 = (uint16_t)(int)(hx * (float)r);
@@ -1486,7 +1544,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             nd.beg = root_beg;
             nd.cnt = cnt_r;
             nd.flags = (cnt_r > 0 ? 1 : 0) | (cnt_r == 1 ? 2 : 0); /* empty roots are erased */
-            if (lane == 0) *qt_node(q, n_ini - 1 - r) = nd;
+            if (lane == 0) qt_store_node(q, n_ini - 1 - r, nd);
             root_beg += cnt_r;
         }
         if (lane == 0) grp_cnt[0][0] = root_beg;
@@ -1499,7 +1557,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
     int32_t *cur = list_a, *nxt = list_b;
     int n_cur = 0;
     for (int idx = 0; idx < n_ini; idx++) {
-        const int fl = rfl(qt_node(q, idx)->flags);
+        const int fl = rfl(qt_load_node(q, idx).flags);
         if (fl & 1) q.size++;
         if ((fl & 1) && !(fl & 2)) {
             if (threadIdx.x == 0) cur[n_cur] = idx;
@@ -1513,16 +1571,25 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
      * through n_nxt the expandable children appended to `nxt`, through n_to_expand their count. */
     auto sweep = [&](auto node_at, int n_list, bool stop_at_n, int &n_nxt, int &n_to_expand) -> bool {
         bool stopped = false;
+        qt_pre pre, pre2; /* this wave's next step (node + records), and the one after (node) */
+        pre.idx = pre2.idx = -1;
+        pre.rec = 0;
+        if (wave < n_list) {
+            qt_fetch_node(q, rfl(node_at(wave)), pre);
+            qt_fetch_records(q, pre);
+        }
+        if (wave + QT_WAVES < n_list) qt_fetch_node(q, rfl(node_at(wave + QT_WAVES)), pre2);
         for (int k0 = 0; k0 < n_list && !stopped && q.error == 0; k0 += QT_WAVES) {
             const int k = k0 + wave;
             const bool have = k < n_list;
             qt_div d;
             int c[4] = {0, 0, 0, 0};
-            int idx = -1;
-            if (have) {
-                idx = rfl(node_at(k));
-                qt_count(q, idx, d, c);
-            }
+            const qt_pre now = pre;
+            const int idx = now.idx;
+            pre = pre2;
+            if (k + QT_WAVES < n_list) qt_fetch_records(q, pre); /* its node record was requested a step ago */
+            if (k + 2 * QT_WAVES < n_list) qt_fetch_node(q, rfl(node_at(k + 2 * QT_WAVES)), pre2);
+            if (have) qt_count(q, now, d, c);
             if (lane == 0) *(int4 *)&grp_cnt[wave][0] = make_int4(c[0], c[1], c[2], c[3]);
             lds_barrier();
             /* every thread replays the sequential bookkeeping of the (up to) four divisions */
@@ -1639,7 +1706,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             }
             const int pos = n_out + before + __popcll(m & lt);
             if (alive && pos < L.sel_cap) {
-                const uint32_t *seg = q.buf[(nd.flags >> 2) & 1] + nd.beg;
+                const uint32_t *seg = qt_buf(q, (nd.flags >> 2) & 1) + nd.beg;
                 uint32_t best = seg[0];
                 for (int k = 1; k < nd.cnt; k++) {
                     const uint32_t r = seg[k];
