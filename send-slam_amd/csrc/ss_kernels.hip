@@ -1243,18 +1243,20 @@ __device__ __forceinline__ void std_sort_items_wave(uint64_t *a, int n, int lane
  * `tmp` is a second array of n items; the caller separates the two phases with its barrier. */
 __device__ __forceinline__ void sort_final_rank(const uint64_t *a, uint64_t *tmp, int n, int tid, int n_threads)
 {
+    /* (key_j < key_i) or (key_j == key_i and j < i) is ONE unsigned 64-bit comparison once the node index in the low 20
+     * bits of an item (not part of the key) is replaced by the item's position */
     for (int i = tid; i < n; i += n_threads) {
         const uint64_t v = a[i];
-        const uint64_t key = v >> 20;
+        const uint64_t mine = (v & ~0xFFFFFull) | (uint32_t)i;
         int rank = 0;
         for (int j0 = 0; j0 < n; j0 += 8) { /* eight broadcast reads in flight */
             uint64_t kj[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) kj[u] = a[imin(j0 + u, n - 1)] >> 20;
+            for (int u = 0; u < 8; u++) kj[u] = a[imin(j0 + u, n - 1)];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int j = j0 + u;
-                rank += (j < n && (kj[u] < key || (kj[u] == key && j < i))) ? 1 : 0;
+                const int j = imin(j0 + u, n - 1); /* a repeat of the last item (j0 + u >= n) compares as itself: counted once below n only */
+                rank += (j0 + u < n && ((kj[u] & ~0xFFFFFull) | (uint32_t)j) < mine) ? 1 : 0;
             }
         }
         tmp[rank] = v;
@@ -1595,9 +1597,15 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             /* every thread replays the sequential bookkeeping of the (up to) four divisions */
             int my_first_child = 0, my_first_nxt = 0;
             bool my_go = false;
-            int4 cnts[QT_WAVES]; /* all counts first: one LDS latency, not one per quadrant of every wave */
+            /* all counts first: one LDS latency, not one per quadrant of every wave -- and made wave-uniform by name
+             * (v_readfirstlane): as values loaded from LDS the compiler must treat them as per-lane, and the bookkeeping
+             * below, which every lane replays identically, came out as ~200 dependent vector instructions and exec-mask
+             * branches per step (2000 cycles on a SIMD this wave has to itself); on the scalar unit it is a fraction */
+            int4 cnts[QT_WAVES];
 #pragma unroll
             for (int w = 0; w < QT_WAVES; w++) cnts[w] = *(const int4 *)&grp_cnt[w][0];
+#pragma unroll
+            for (int w = 0; w < QT_WAVES; w++) cnts[w] = make_int4(rfl(cnts[w].x), rfl(cnts[w].y), rfl(cnts[w].z), rfl(cnts[w].w));
 #pragma unroll
             for (int w = 0; w < QT_WAVES; w++) {
                 if (k0 + w >= n_list) break;
