@@ -1442,22 +1442,23 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
             place(rec[u], i < d.cnt ? (SS_PX(rec[u]) >= d.xm ? 1 : 0) | (SS_PY(rec[u]) >= d.ym ? 2 : 0) : 4);
         }
     }
-    const int rx0[4] = {d.x0, d.xm, d.x0, d.xm}, rx1[4] = {d.xm, d.x1, d.xm, d.x1};
-    const int ry0[4] = {d.y0, d.y0, d.ym, d.ym}, ry1[4] = {d.ym, d.ym, d.y1, d.y1};
-    int made = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (c[k] > 0) {
+    /* the (up to) four child records: lane k writes child k, so the block is five store instructions, not twenty issued
+     * one after the other by lane 0 */
+    if (lane < 4) {
+        const int k = lane;
+        const int ck = k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3];
+        const int ok = k == 0 ? o[0] : k == 1 ? o[1] : k == 2 ? o[2] : o[3];
+        const int before = (k > 0 && c[0] > 0) + (k > 1 && c[1] > 0) + (k > 2 && c[2] > 0); /* non-empty quadrants before k */
+        if (ck > 0) {
             ss_qnode ch;
-            ch.x0 = (uint16_t)rx0[k];
-            ch.x1 = (uint16_t)rx1[k];
-            ch.y0 = (uint16_t)ry0[k];
-            ch.y1 = (uint16_t)ry1[k];
-            ch.beg = d.beg + o[k];
-            ch.cnt = c[k];
-            ch.flags = 1 | (c[k] == 1 ? 2 : 0) | ((d.b ^ 1) << 2);
-            if (lane == 0) qt_store_node(q, first_child + made, ch);
-            made++;
+            ch.x0 = (uint16_t)((k & 1) ? d.xm : d.x0);
+            ch.x1 = (uint16_t)((k & 1) ? d.x1 : d.xm);
+            ch.y0 = (uint16_t)((k & 2) ? d.ym : d.y0);
+            ch.y1 = (uint16_t)((k & 2) ? d.y1 : d.ym);
+            ch.beg = d.beg + ok;
+            ch.cnt = ck;
+            ch.flags = 1 | (ck == 1 ? 2 : 0) | ((d.b ^ 1) << 2);
+            qt_store_node(q, first_child + before, ch);
         }
     }
     if (lane == 0) qt_store_flags(q, idx, d.flags & ~1); /* lNodes.erase */
@@ -1631,15 +1632,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             }
             if (have && my_go && q.error == 0) {
                 qt_scatter(q, idx, d, c, my_first_child);
-                if (lane == 0) {
-                    int child = my_first_child, pos = my_first_nxt;
-#pragma unroll
-                    for (int qd = 0; qd < 4; qd++) {
-                        if (c[qd] > 0) {
-                            if (c[qd] > 1) nxt[pos++] = child;
-                            child++;
-                        }
-                    }
+                if (lane < 4) { /* lane k appends child k to the next list if it can be divided again */
+                    const int k = lane;
+                    const int ck = k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3];
+                    const int child = my_first_child + (k > 0 && c[0] > 0) + (k > 1 && c[1] > 0) + (k > 2 && c[2] > 0);
+                    const int pos = my_first_nxt + (k > 0 && c[0] > 1) + (k > 1 && c[1] > 1) + (k > 2 && c[2] > 1);
+                    if (ck > 1) nxt[pos] = child;
                 }
             }
             lds_barrier();
