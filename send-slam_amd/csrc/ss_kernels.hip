@@ -1593,25 +1593,33 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const ss_geom *__restri
             if (k + QT_WAVES < n_list) qt_fetch_records(q, pre); /* its node record was requested a step ago */
             if (k + 2 * QT_WAVES < n_list) qt_fetch_node(q, rfl(node_at(k + 2 * QT_WAVES)), pre2);
             if (have) qt_count(q, now, d, c);
-            if (lane == 0) *(int4 *)&grp_cnt[wave][0] = make_int4(c[0], c[1], c[2], c[3]);
+            /* what the other waves need of this division: how many children (non-empty quadrants) and how many of them can be
+             * divided again, in one word; the four words are one 16-byte LDS read */
+            if (lane == 0)
+                grp_cnt[wave >> 2][wave & 3] = ((c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0)) | (((c[0] > 1) + (c[1] > 1) + (c[2] > 1) + (c[3] > 1)) << 8);
             lds_barrier();
             /* every thread replays the sequential bookkeeping of the (up to) four divisions */
             int my_first_child = 0, my_first_nxt = 0;
             bool my_go = false;
-            /* all counts first: one LDS latency, not one per quadrant of every wave -- and made wave-uniform by name
-             * (v_readfirstlane): as values loaded from LDS the compiler must treat them as per-lane, and the bookkeeping
-             * below, which every lane replays identically, came out as ~200 dependent vector instructions and exec-mask
-             * branches per step (2000 cycles on a SIMD this wave has to itself); on the scalar unit it is a fraction */
-            int4 cnts[QT_WAVES];
+            /* made wave-uniform by name (v_readfirstlane): as values loaded from LDS the compiler must treat them as per-lane,
+             * and the bookkeeping below, which every lane replays identically, came out as ~200 dependent vector instructions
+             * and exec-mask branches per step (2000 cycles on a SIMD this wave has to itself); on the scalar unit, and from
+             * the two sums per division instead of its four counts, it is a fraction */
+            static_assert(QT_WAVES <= 4 || QT_WAVES == 8, "grp_cnt rows of four words");
+            int words[QT_WAVES];
 #pragma unroll
-            for (int w = 0; w < QT_WAVES; w++) cnts[w] = *(const int4 *)&grp_cnt[w][0];
-#pragma unroll
-            for (int w = 0; w < QT_WAVES; w++) cnts[w] = make_int4(rfl(cnts[w].x), rfl(cnts[w].y), rfl(cnts[w].z), rfl(cnts[w].w));
+            for (int w4 = 0; w4 < QT_WAVES; w4 += 4) {
+                const int4 v = *(const int4 *)&grp_cnt[w4 / 4][0];
+                words[w4] = rfl(v.x);
+                if (w4 + 1 < QT_WAVES) words[w4 + 1] = rfl(v.y);
+                if (w4 + 2 < QT_WAVES) words[w4 + 2] = rfl(v.z);
+                if (w4 + 3 < QT_WAVES) words[w4 + 3] = rfl(v.w);
+            }
 #pragma unroll
             for (int w = 0; w < QT_WAVES; w++) {
                 if (k0 + w >= n_list) break;
-                const int made = (cnts[w].x > 0) + (cnts[w].y > 0) + (cnts[w].z > 0) + (cnts[w].w > 0);
-                const int expandable = (cnts[w].x > 1) + (cnts[w].y > 1) + (cnts[w].z > 1) + (cnts[w].w > 1);
+                const int made = words[w] & 0xFF;
+                const int expandable = words[w] >> 8;
                 if (q.n_nodes + 4 > q.node_cap || n_nxt + expandable > list_cap) {
                     q.error = -5;
                     break;
