@@ -1419,13 +1419,17 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
     run[2] = c[0] + c[1];
     run[3] = c[0] + c[1] + c[2];
     const int o[4] = {run[0], run[1], run[2], run[3]};
+    /* one store per chunk of 64 records: a lane picks the ballot of ITS quadrant and the quadrant's running offset (selects)
+     * instead of four masked stores, each with its own prefix and exec-mask switch */
     auto place = [&](uint32_t rec, int quad) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t m = __ballot(quad == k);
-            if (quad == k) dst[run[k] + __popcll(m & lt)] = rec;
-            run[k] += __popcll(m);
-        }
+        const uint64_t m0 = __ballot(quad == 0), m1 = __ballot(quad == 1), m2 = __ballot(quad == 2), m3 = __ballot(quad == 3);
+        const uint64_t mine = quad == 0 ? m0 : quad == 1 ? m1 : quad == 2 ? m2 : m3;
+        const int base = quad == 0 ? run[0] : quad == 1 ? run[1] : quad == 2 ? run[2] : run[3];
+        if (quad < 4) dst[base + __popcll(mine & lt)] = rec;
+        run[0] += __popcll(m0);
+        run[1] += __popcll(m1);
+        run[2] += __popcll(m2);
+        run[3] += __popcll(m3);
     };
     place(d.rec0, d.q0);
     for (int base = WAVE; base < d.cnt; base += 4 * WAVE) {
