@@ -1329,6 +1329,19 @@ __device__ __forceinline__ ss_qnode qt_load_node(const qt_ctx &q, int idx)
     __builtin_memcpy(&n, w, sizeof(w));
     return n;
 }
+/* a node record that is known to live in the global table (index >= QT_LDS_NODES): 16 + 4 bytes, two stores */
+typedef uint32_t qt_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(1))) qt_u32x4 qt_gu32x4;
+__device__ __forceinline__ void qt_store_node_global(const qt_ctx &q, int idx, const ss_qnode &n)
+{
+    uint32_t w[5];
+    __builtin_memcpy(w, &n, sizeof(w));
+    uint32_t *p = (uint32_t *)(q.nodes + idx);
+    qt_u32x4 v;
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    *(qt_gu32x4 *)p = v;
+    ((qt_gu32 *)p)[4] = w[4];
+}
 __device__ __forceinline__ void qt_store_flags(const qt_ctx &q, int idx, int flags)
 {
     if (idx < QT_LDS_NODES) ((qt_lu32 *)(uint32_t *)(q.lds_nodes + idx))[4] = (uint32_t)flags;
@@ -1462,7 +1475,8 @@ __device__ __forceinline__ void qt_scatter(const qt_ctx &q, int idx, const qt_di
             ch.beg = d.beg + ok;
             ch.cnt = ck;
             ch.flags = 1 | (ck == 1 ? 2 : 0) | ((d.b ^ 1) << 2);
-            qt_store_node(q, first_child + before, ch);
+            if (first_child >= QT_LDS_NODES) qt_store_node_global(q, first_child + before, ch); /* wave-uniform: all but the first nodes */
+            else qt_store_node(q, first_child + before, ch);
         }
     }
     if (lane == 0) qt_store_flags(q, idx, d.flags & ~1); /* lNodes.erase */
