@@ -10,18 +10,26 @@ contexts (camera batches in flight, each with its own stream and buffers).  With
 runs the same steps on its own camera batches (cameras shard one per GPU, no data-path collective):
 weak scaling, value = frames all ranks processed / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]        N > 1 without a launcher: bench.py starts its N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python -m torch.distributed.run ... bench.py --workload stereo|loop_closure   (configs 4 and 5)
+    python bench.py --gpus 2 --workload stereo [--exchange native|rccl]    config 4
+    python bench.py --gpus N --workload loop_closure [--exchange ...]      config 5
+
+Timing: R rounds of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced
+over the ranks; R is chosen from the first round so that the rounds together time >= 0.5 s whatever K is (at least 3).
+value = units all ranks processed in a round / the MEDIAN round's time; value_spread = min / median / max over the rounds.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  sustained              (K < 500) one region of 1000 steps, the rate of a pipeline that stays full, with the rate of each 1/25th
+  ranks_reported_by_backend  N > 1 (and forced world-1 groups): world size and an all-reduce of ones through the backend
+  single_gpu_exchange    N = 1: configs 4 and 5 as child processes at world size 1 -- through a real "nccl" (RCCL) process
+                         group (SENDSLAM_BENCH_FORCE_DIST=1) and through the C ABI's own exchange (ss_xchg_*)
   roofline               dominant kernel: ALGORITHMIC bytes per launch / HIP-event mean duration on its own stream
   valu_roofline          the same kernel against the resource that binds it (integer VALU issue)
   match_roofline         the Hamming-match kernel of the metric (2000 x 2000 per frame) against the int8 MFMA peak
   match_stream_roofline  the Hamming-match kernel in the database-streaming regime (1 and 4 queries against 20 M
                          descriptors = 640 MB): achieved HBM GB/s against the 8 TB/s peak -- the north star's
                          ">= 60 % HBM roofline on the Hamming-match kernel"
-  value_spread           rate of each 1/25th of the timed region (HIP events, no drain between them)
   host_pipeline          the same step fed from HOST memory through the pinned ring of the C ABI (ss_pipe_*):
                          frames/s and PCIe GB/s, copies overlapped with the kernels.  Never `value`.
   kernels                per-stage durations
@@ -159,22 +167,84 @@ def dist_setup(world):
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    if world > 1:
+    if use_dist(world):
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("SENDSLAM_BENCH_DIST_TIMEOUT", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # RCCL over xGMI
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)  # RCCL over xGMI
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     return rank, local_rank, dev, backend
+
+
+def use_dist(world):
+    """a process group exists for every multi-rank run, and at world size 1 under SENDSLAM_BENCH_FORCE_DIST=1: the
+    collectives of the stereo / loop-closure steps then run through RCCL ("nccl") on ONE GPU, so that branch has
+    executed before an 8-GPU node sees it"""
+    return world > 1 or os.environ.get("SENDSLAM_BENCH_FORCE_DIST") == "1"
+
+
+def backend_world(world, dev, backend):
+    """the rank count the backend itself reports: an all-reduce of ones (through RCCL on the GPUs)"""
+    import torch
+    import torch.distributed as dist
+    if not use_dist(world):
+        return None
+    t = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    return {"backend": backend, "world_size": dist.get_world_size(), "allreduce_of_ones": int(t.item())}
 
 
 def max_over_ranks(elapsed, world, dev, backend):
     import torch
     import torch.distributed as dist
-    if world <= 1:
+    if not use_dist(world):
         return elapsed
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+MIN_REGION_S = 0.5  # whatever --steps is, the rounds together time at least this long
+
+
+def timed_rounds(run_steps, steps, drain, world, dev, backend, max_rounds=400):
+    """R rounds of EXACTLY `steps` steps.  Every round is bracketed by barrier + torch.cuda.synchronize() on both sides and
+    its time is the MAX over ranks; R comes from the first round (itself a timed round, after the warm-up) so that the
+    rounds together last >= MIN_REGION_S, at least 3.  The max-reduced time is the same number on every rank, so every
+    rank computes the same R.  Returns the list of round times in seconds."""
+    import math
+    import torch
+    import torch.distributed as dist
+    d = use_dist(world)
+
+    def one():
+        if d:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        drain()
+        torch.cuda.synchronize()
+        if d:
+            dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+    times = [one()]
+    rounds = min(max_rounds, max(3, int(math.ceil(MIN_REGION_S / max(times[0], 1e-6)))))
+    if os.environ.get("SENDSLAM_BENCH_ROUNDS"):
+        rounds = max(1, int(os.environ["SENDSLAM_BENCH_ROUNDS"]))
+    for _ in range(rounds - 1):
+        times.append(one())
+    return times
+
+
+def round_summary(times, units_per_round, unit):
+    """value = the median round's rate; spread over the rounds"""
+    srt = sorted(times)
+    med = srt[len(srt) // 2]
+    return med, {"rounds": len(times), "median": round(units_per_round / med, 2), "min": round(units_per_round / srt[-1], 2),
+                 "max": round(units_per_round / srt[0], 2), "unit": unit,
+                 "round_ms": {"median": round(med * 1e3, 4), "min": round(srt[0] * 1e3, 4), "max": round(srt[-1] * 1e3, 4)}}
 
 
 def stage_roofline(stats, name, peak=HBM_PEAK_GBS):
@@ -210,6 +280,9 @@ def bench_loop_closure(a):
     # the expanding kernel (k_match_mfma<2>) instead
     dbx = None if os.environ.get("SENDSLAM_LC_PACKED") == "1" else multi.expand_database(ctx, db)
     kw = {} if dbx is None else {"db_expanded": dbx, "n_db": e - b}
+    xchg = make_exchange(a, binding, rank, world, local_rank, nq * 32)
+    if xchg is not None:
+        kw["xchg"] = xchg
     _q = multi.loop_closure_query_device
     multi_query = lambda: _q(ctx, query, db, b, out=out, **kw)  # noqa: E731
     for _ in range(max(a.warmup, 1)):
@@ -217,19 +290,15 @@ def bench_loop_closure(a):
     ctx.synchronize()
     ctx.profile(True)
     ctx.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        multi_query()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+
+    def run_steps(k):
+        for _ in range(k):
+            multi_query()
+    times = timed_rounds(run_steps, steps, ctx.synchronize, world, dev, backend)
+    elapsed, spread = round_summary(times, steps, "queries/s")
     stats = ctx.stats()
     ctx.profile(False)
+    reported = backend_world(world, dev, backend)
     if rank == 0:
         mk = next((s for s in stats if s["name"] == "match"), None)
         pairs = float(nq) * (e - b)
@@ -242,27 +311,49 @@ def bench_loop_closure(a):
                     "kernel_ms": round(mk["mean_ms"], 4), "traffic": None}
         print(json.dumps({
             "metric": "loop-closure queries/sec (2000 descriptors vs 10k-keyframe database)", "value": round(steps / elapsed, 3),
-            "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "unit": "queries/s", "n_gpus": world, "steps": steps, "rounds": len(times), "warmup": a.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"loop closure: {nq}-descriptor query vs {n_db} descriptors (640 MB) sharded over {world} GPU(s), "
                                    "raw local match -> 8-byte records, all_gather, fold kernel", "parallelism": f"db slabs x {world}",
-                       "database_format": "packed 32 B rows" if dbx is None else "expanded once to 128 B rows of FP4 +-1 (matrix-core operand)"},
+                       "database_format": "packed 32 B rows" if dbx is None else "expanded once to 128 B rows of FP4 +-1 (matrix-core operand)",
+                       "exchange": exchange_name(a, world), "backend": backend if use_dist(world) else None},
+            "timed_region_s": round(sum(times), 4), "value_spread": spread, "ranks_reported_by_backend": reported,
             "roofline": roof, "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
             "pairs_per_s": float(f"{nq * n_db * steps / elapsed:.4g}")}))
+    if xchg is not None:
+        xchg.close()
     ctx.close()
-    if world > 1:
+    if use_dist(world):
         dist.destroy_process_group()
+
+
+def exchange_name(a, world):
+    if not use_dist(world) and a.exchange != "native":
+        return None
+    return "native (ss_xchg: peer-mapped slabs, direct writes + flags)" if a.exchange == "native" else "torch.distributed collectives"
+
+
+def make_exchange(a, binding, rank, world, local_rank, max_bytes):
+    """--exchange native: the C ABI's own all-gather (ss_xchg_*: every rank writes its block straight into every peer's
+    IPC-mapped slab over xGMI and raises a flag; no PyTorch, no RCCL in the data path).  The rendezvous (a Unix socket
+    path) comes from the master port, so every rank derives the same one."""
+    if a.exchange != "native":
+        return None
+    path = os.environ.get("SENDSLAM_XCHG_PATH") or f"/tmp/sendslam_xchg_{os.environ.get('MASTER_PORT', '29533')}_{a.workload}"
+    return binding.Exchange(local_rank, rank, world, max_bytes, path)
 
 
 def bench_stereo(a):
     """Config 4 of BASELINE.json: left / right 1920x1080 cameras on two GPUs.  A step = each rank extracts a batch of
     frames of ITS eye, one all_gather of the fixed-size descriptor blocks ([B][kp_capacity][32] + counts) over xGMI,
     then each rank matches its frames against the peer eye's frames of the same instant (ss_match_pairs_device).
-    Everything is ordered on the context's stream; value = stereo pairs per second."""
+    Everything is ordered on the context's stream; value = stereo pairs per second.  World size 1 is accepted under
+    SENDSLAM_BENCH_FORCE_DIST=1 only (one-GPU execution of the same collectives: the "peer" eye is the rank's own)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != 2:
-        sys.exit("bench.py --workload stereo needs exactly 2 ranks (torch.distributed.run --nproc-per-node 2)")
+    if world != 2 and not (world == 1 and (use_dist(world) or a.exchange == "native")):
+        sys.exit("bench.py --workload stereo needs exactly 2 ranks (bench.py --gpus 2 --workload stereo, or torch.distributed.run "
+                 "--nproc-per-node 2); world size 1 only with SENDSLAM_BENCH_FORCE_DIST=1")
     rank, local_rank, dev, backend = dist_setup(world)
     import torch
     import torch.distributed as dist
@@ -287,25 +378,33 @@ def bench_stereo(a):
         return torch.as_tensor(_Wrap(), device=dev)
     own_desc = dev_tensor(view.descriptors, (B, kcap, 32), torch.uint8)
     own_n = dev_tensor(view.n_keypoints, (B,), torch.int32)
-    gathered_desc = torch.empty((2, B, kcap, 32), dtype=torch.uint8, device=dev)
-    gathered_n = torch.empty((2, B), dtype=torch.int32, device=dev)
+    gathered_desc = torch.empty((world, B, kcap, 32), dtype=torch.uint8, device=dev)
+    gathered_n = torch.empty((world, B), dtype=torch.int32, device=dev)
     o_idx = torch.empty((B, kcap), dtype=torch.int32, device=dev)
     o_d1 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
     o_d2 = torch.empty((B, kcap), dtype=torch.int16, device=dev)
-    peer = 1 - rank
+    peer = (world - 1) - rank
+    blk = B * kcap * 32
+    # native exchange: ONE message per step = the descriptor blocks followed by the B counts
+    xchg = make_exchange(a, binding, rank, world, local_rank, blk + 4 * B)
 
     def step():
         ctx.extract_batch_device(d_frames.data_ptr(), B, w, h)
+        if xchg is not None:
+            base, stride = xchg.allgather(ctx, [(view.descriptors, blk), (view.n_keypoints, 4 * B)])
+            ctx.match_pairs_device(view.descriptors, view.n_keypoints, base + peer * stride, base + peer * stride + blk,
+                                   B, kcap, o_idx.data_ptr(), o_d1.data_ptr(), o_d2.data_ptr())
+            return
         with multi.on_ctx_stream(ctx, dev):
             if backend == "nccl":
                 dist.all_gather_into_tensor(gathered_desc, own_desc)
                 dist.all_gather_into_tensor(gathered_n, own_n)
             else:  # CPU rehearsal of the exchange
                 ctx.synchronize()
-                outs = [torch.empty((B, kcap, 32), dtype=torch.uint8) for _ in range(2)]
+                outs = [torch.empty((B, kcap, 32), dtype=torch.uint8) for _ in range(world)]
                 dist.all_gather(outs, own_desc.cpu())
                 gathered_desc.copy_(torch.stack(outs))
-                outs = [torch.empty((B,), dtype=torch.int32) for _ in range(2)]
+                outs = [torch.empty((B,), dtype=torch.int32) for _ in range(world)]
                 dist.all_gather(outs, own_n.cpu())
                 gathered_n.copy_(torch.stack(outs))
             ctx.match_pairs_device(own_desc.data_ptr(), own_n.data_ptr(), gathered_desc[peer].data_ptr(), gathered_n[peer].data_ptr(),
@@ -317,17 +416,15 @@ def bench_stereo(a):
     ctx.synchronize()
     ctx.profile(True)
     ctx.profile_reset()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+
+    def run_steps(k):
+        for _ in range(k):
+            step()
+    times = timed_rounds(run_steps, steps, ctx.synchronize, world, dev, backend)
+    elapsed, spread = round_summary(times, B * steps, "pairs/s")
     stats = ctx.stats()
     ctx.profile(False)
+    reported = backend_world(world, dev, backend)
     # sanity on the measured configuration: most left keypoints find their right-eye partner 24 px away
     n_own = own_n.cpu().numpy()
     idx = o_idx.cpu().numpy()
@@ -335,15 +432,21 @@ def bench_stereo(a):
     if rank == 0:
         print(json.dumps({
             "metric": "stereo pairs/sec ORB extract + cross-camera match @1920x1080, 2000 kp/eye", "value": round(B * steps / elapsed, 2),
-            "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "unit": "pairs/s", "n_gpus": world, "steps": steps, "rounds": len(times), "warmup": a.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"stereo {w}x{h}: one eye per GPU, batches of {B} frames, all_gather of {B * kcap * 32} B descriptor blocks + counts, "
-                                   "cross-eye match", "parallelism": "2 ranks, one all_gather per step", "backend": backend},
+                                   "cross-eye match" + (" (world size 1: the peer eye is the rank's own)" if world == 1 else ""),
+                       "parallelism": f"{world} rank(s), one all_gather per step", "backend": backend if use_dist(world) else None,
+                       "exchange": exchange_name(a, world)},
+            "timed_region_s": round(sum(times), 4), "value_spread": spread, "ranks_reported_by_backend": reported,
             "roofline": stage_roofline(stats, "fast_blur_nms"),
             "kernels": [{"name": s["name"], "mean_ms": round(s["mean_ms"], 5), "launches": s["launches"]} for s in stats],
             "fraction_of_keypoints_matched_across_eyes": round(matched, 3)}))
+    if xchg is not None:
+        xchg.close()
     ctx.close()
-    dist.destroy_process_group()
+    if use_dist(world):
+        dist.destroy_process_group()
 
 
 def bench_match_stream(binding, torch, dev, local_rank, launches=24):
@@ -457,6 +560,76 @@ def bench_host_pipeline(binding, frames_sets, w, h, nf, B, local_rank, depth=4, 
                     "pinned slot (PCIe + kernels only)"}
 
 
+def exchange_legs(timeout_s=240):
+    import socket
+    import subprocess
+    res = {}
+    for name, args, env_extra in (
+            ("loop_closure_rccl_world1", ["--workload", "loop_closure", "--steps", "10", "--warmup", "2"], {"SENDSLAM_BENCH_FORCE_DIST": "1"}),
+            ("stereo_rccl_world1", ["--workload", "stereo", "--steps", "10", "--warmup", "2"], {"SENDSLAM_BENCH_FORCE_DIST": "1"}),
+            ("loop_closure_native_world1", ["--workload", "loop_closure", "--exchange", "native", "--steps", "10", "--warmup", "2"], {}),
+            ("stereo_native_world1", ["--workload", "stereo", "--exchange", "native", "--steps", "10", "--warmup", "2"], {})):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", SENDSLAM_BENCH_DIST_TIMEOUT="60", **env_extra)
+        env.pop("SENDSLAM_BENCH_BACKEND", None)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + args, env=env, capture_output=True, text=True,
+                               timeout=timeout_s)
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                res[name] = {"ok": False, "returncode": r.returncode, "stderr_tail": r.stderr[-600:]}
+                continue
+            j = json.loads(line)
+            res[name] = {"ok": True, "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "rounds": j.get("rounds"),
+                         "backend": j["config"].get("backend"), "exchange": j["config"].get("exchange"),
+                         "ranks_reported_by_backend": j.get("ranks_reported_by_backend"),
+                         "kernels": {k["name"]: k["mean_ms"] for k in j.get("kernels", [])}}
+            if "fraction_of_keypoints_matched_across_eyes" in j:
+                res[name]["fraction_of_keypoints_matched_across_eyes"] = j["fraction_of_keypoints_matched_across_eyes"]
+        except subprocess.TimeoutExpired:
+            res[name] = {"ok": False, "error": f"no result within {timeout_s} s"}
+    return res
+
+
+def self_launch(n):
+    import signal
+    import socket
+    import subprocess
+    one_device = os.environ.get("SENDSLAM_BENCH_ONE_DEVICE") == "1"
+    if not one_device:
+        import torch
+        have = torch.cuda.device_count()  # no HIP context is created by this call
+        if have < n:
+            sys.exit(f"bench.py --gpus {n}: this node shows {have} GPU(s)")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # a rank failed: the others would wait for it in a collective
+                    procs[q].send_signal(signal.SIGTERM)
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -476,7 +649,17 @@ def main():
     ap.add_argument("--workload", default="extract_match", choices=["extract_match", "loop_closure", "stereo"],
                     help="extract_match = the BASELINE.json metric (default); stereo = config 4 (2 ranks); loop_closure = config 5: one "
                          "2000-descriptor query against a 10 000-keyframe descriptor database sharded over the ranks (strong scaling)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "native"],
+                    help="stereo / loop_closure: rccl = torch.distributed collectives (RCCL over xGMI; gloo in rehearsals), native = the C "
+                         "ABI's own peer-write all-gather (ss_xchg_*)")
     a = ap.parse_args()
+
+    # python bench.py --gpus N (N > 1) started plainly: this process becomes the launcher.  It starts N ranks of itself
+    # BEFORE making any HIP call (device_count() does not initialise the GPU), never exec()s, relays rank 0's JSON line
+    # (the children share its stdout) and exits with the first failing rank's code.  Under torch.distributed.run
+    # (WORLD_SIZE set) nothing of this runs.
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a.gpus)
     if a.workload == "loop_closure":
         return bench_loop_closure(a)
     if a.workload == "stereo":
@@ -484,10 +667,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
     w, h, nf = a.width, a.height, a.features
     B = a.batch or 64
     steps = a.steps or 1000
@@ -540,62 +720,27 @@ def main():
     for c in ctxs:
         c.synchronize()
 
-    # rate of each 1/25th of the timed region, from events recorded on the contexts' streams (no drain in between)
-    n_chunks = 25 if steps >= 100 else 0
-    chunk_ev = []
-    ext = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs]
-
-    def mark():
-        evs = []
-        for s_ in ext:
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(s_)
-            evs.append(e)
-        chunk_ev.append(evs)
-
-    # per-kernel HIP events on each context's own stream, live over the timed region (SENDSLAM_BENCH_NO_EVENTS=1
+    # per-kernel HIP events on each context's own stream, live over the timed rounds (SENDSLAM_BENCH_NO_EVENTS=1
     # switches them off to measure what they cost)
     live_events = os.environ.get("SENDSLAM_BENCH_NO_EVENTS") != "1"
     for c in ctxs:
         c.profile(live_events)
         c.profile_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if n_chunks:
-        bounds = [round(steps * j / n_chunks) for j in range(n_chunks + 1)]
-        mark()
-        for j in range(n_chunks):
-            for i in range(bounds[j], bounds[j + 1]):
-                step(i)
-            mark()
-    else:
-        for i in range(steps):
-            step(i)
-    for c in ctxs:
-        c.synchronize()  # drains the context's stream and checks the per-frame error words
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, dev, backend)
+    next_step = [max(a.warmup, n_ctx)]  # the step counter runs on over the rounds: contexts and frame sets keep rotating
 
-    spread = None
-    if n_chunks:
-        rates = []
-        for j in range(n_chunks):
-            # chunk j = from the latest of the start marks to the latest of the end marks over the contexts
-            ref = chunk_ev[0][0]
-            t_start = max(ref.elapsed_time(e) for e in chunk_ev[j])
-            t_end = max(ref.elapsed_time(e) for e in chunk_ev[j + 1])
-            n_fr = (bounds[j + 1] - bounds[j]) * B
-            if t_end > t_start:
-                rates.append(n_fr / ((t_end - t_start) * 1e-3))
-        rates.sort()
-        if rates:
-            spread = {"chunks": len(rates), "steps_per_chunk": steps // n_chunks, "median": round(rates[len(rates) // 2], 1),
-                      "min": round(rates[0], 1), "max": round(rates[-1], 1), "unit": "frames/s per rank"}
+    def run_steps(k):
+        for i in range(next_step[0], next_step[0] + k):
+            step(i)
+        next_step[0] += k
+
+    def drain():
+        for c in ctxs:
+            c.synchronize()  # drains the context's stream and checks the per-frame error words
+    # R rounds of exactly `steps` steps, each bracketed by barrier + synchronize and max-reduced over the ranks; together
+    # >= 0.5 s whatever --steps is.  value = the median round.
+    times = timed_rounds(run_steps, steps, drain, world, dev, backend)
+    elapsed, spread = round_summary(times, B * steps * world, "frames/s")
+    reported = backend_world(world, dev, backend)
 
     # per-kernel HIP-event statistics of the timed loop (summed over the contexts)
     def merged_stats(cs):
@@ -613,6 +758,51 @@ def main():
     stats = merged_stats(ctxs)
     for c in ctxs:
         c.profile(False)
+
+    # A round of few steps pays the ramp of its first batch and the latency tail of its last one (the quadtree of the
+    # last batch runs with nothing beside it).  The rate the pipeline sustains once full: one region of >= 1000 steps,
+    # bracketed like a round, with the rate of each 1/25th of it from events recorded on the contexts' streams (no drain
+    # in between).  Reported next to `value`, never instead.
+    sustained = None
+    if not a.timed_only and steps < 500:
+        s_steps, n_chunks = 1000, 25
+        ext = [torch.cuda.ExternalStream(c.stream(), device=dev) for c in ctxs]
+        chunk_ev = []
+
+        def mark():
+            evs = []
+            for s_ in ext:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(s_)
+                evs.append(e)
+            chunk_ev.append(evs)
+        bounds = [round(s_steps * j / n_chunks) for j in range(n_chunks + 1)]
+        if use_dist(world):
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mark()
+        for j in range(n_chunks):
+            run_steps(bounds[j + 1] - bounds[j])
+            mark()
+        drain()
+        torch.cuda.synchronize()
+        if use_dist(world):
+            dist.barrier()
+        s_el = max_over_ranks(time.perf_counter() - t0, world, dev, backend)
+        rates = []
+        for j in range(n_chunks):
+            # chunk j = from the latest of the start marks to the latest of the end marks over the contexts
+            ref = chunk_ev[0][0]
+            t_start = max(ref.elapsed_time(e) for e in chunk_ev[j])
+            t_end = max(ref.elapsed_time(e) for e in chunk_ev[j + 1])
+            if t_end > t_start:
+                rates.append((bounds[j + 1] - bounds[j]) * B / ((t_end - t_start) * 1e-3))
+        rates.sort()
+        sustained = {"value": round(B * s_steps * world / s_el, 2), "unit": "frames/s", "steps": s_steps, "ms_per_step": round(s_el / s_steps * 1e3, 4),
+                     "region_s": round(s_el, 4),
+                     "chunks": None if not rates else {"n": len(rates), "median": round(rates[len(rates) // 2], 1), "min": round(rates[0], 1),
+                                                       "max": round(rates[-1], 1), "unit": "frames/s per rank"}}
 
     # parity of the measured configuration: EVERY context's last timed batch against the oracle (frame 1 + its own
     # index of that batch: the oracle costs 0.1 s per frame), then all frames of the baseline leg on context 0
@@ -703,10 +893,17 @@ def main():
         if world == 1:
             host_pipe = bench_host_pipeline(binding, frames, w, h, nf, B, local_rank)
 
+    if use_dist(world):
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
+
+    # Configs 4 and 5 on this one GPU, each as a child process (started, never exec'ed into) at world size 1 with a real
+    # "nccl" process group: the all_gather / broadcast of their steps go through RCCL, so that branch has executed on the
+    # hardware the line was measured on; then the same steps over the C ABI's own exchange.  Never `value`.
+    single_gpu_exchange = None
+    if world == 1 and not a.timed_only and os.environ.get("SENDSLAM_BENCH_NO_EXCHANGE_LEGS") != "1":
+        single_gpu_exchange = exchange_legs()
 
     kernels = []
     for s in stats:
@@ -775,8 +972,13 @@ def main():
         if insts:
             peak = json.load(open(pk_path))["xor_popc_lane_ops_per_s"]
             ach = insts * B * 64 / (dom["isolated_mean_ms"] * 1e-3)
+            arch_peak = 256 * 4 * 2.4e9 / 2 * 64  # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32
             valu_roofline = {"kernel": dom["name"], "bound": "int_valu", "achieved": float(f"{ach:.4g}"), "peak": peak,
-                             "unit": "lane-ops/s", "frac": round(ach / peak, 4), "valu_wave_instructions_per_launch": int(insts * B)}
+                             "unit": "lane-ops/s", "frac": round(ach / peak, 4), "valu_wave_instructions_per_launch": int(insts * B),
+                             "peak_is": "the measured issue rate of this path's instruction class (v_bcnt / v_perm / v_dot4 / v_pk_*: 4.05 cycles "
+                                        "per wave64 instruction and SIMD, profiles/r01_peaks.json)",
+                             "architectural_peak": arch_peak, "frac_of_architectural_peak": round(ach / arch_peak, 4),
+                             "architectural_peak_is": "2 cycles per wave64 instruction and SIMD at 2.4 GHz, 1024 SIMDs"}
 
     total_frames = B * steps * world
     out = {
@@ -790,7 +992,8 @@ def main():
                    "n_features": nf, "n_levels": 8, "scale_factor": 1.2,
                    "match": "self-match all-pairs, j==i excluded, TH 50, ratio 9/10",
                    "parallelism": f"one camera batch per GPU x {world}, no collective"},
-        "timed_region_s": round(elapsed, 4), "value_spread": spread,
+        "rounds": len(times), "timed_region_s": round(sum(times), 4), "value_spread": spread, "sustained": sustained,
+        "ranks_reported_by_backend": reported, "single_gpu_exchange": single_gpu_exchange,
         "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline,
         "match_stream_roofline": match_stream, "host_pipeline": host_pipe, "kernels": kernels, "cpu_baseline": cpu_obj,
         "parity_checked_vs_oracle": parity,
@@ -799,8 +1002,6 @@ def main():
         "track_frame_host_to_host_ms": None if track_ms is None else round(track_ms, 3), "track_ok_frames_of_14": track_ok,
     }
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

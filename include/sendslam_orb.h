@@ -25,6 +25,8 @@
  *                              extracted (front door read-ahead of queued frames)
  *   ss_match_partial_device /  the local and the cross-shard half of a query against a database
  *   ss_match_fold_device       partitioned over GPUs
+ *   ss_xchg_*                  the exchange step of configs 4 / 5 (all-gather, broadcast) as direct peer writes; no
+ *                              counterpart in the reference (one TCP link :387-388)
  *   ss_match*                  ORBmatcher::DescriptorDistance + best/second-best search inside
  *                              TrackMonocular :594 (all-pairs rule: SURVEY.md Appendix A.6)
  *   ss_track                   TrackMonocular :594 -> Twc, tracking state :596 (bounded monocular
@@ -50,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 3
+#define SS_ABI_VERSION 4
 #define SS_MAX_LEVELS 16
 #define SS_DESC_BYTES 32
 
@@ -254,6 +256,34 @@ int ss_match_partial_device(ss_ctx *ctx, const void *d_query, int n_query, const
                             int64_t row_offset, void *d_part);
 int ss_match_fold_device(ss_ctx *ctx, const void *d_parts, int n_parts, int n_query, int th, int ratio_num,
                          int ratio_den, void *d_idx, void *d_d1, void *d_d2);
+/* same, part p at d_parts + p * part_stride_bytes (a multiple of 8, >= n_query * 8): the layout ss_xchg_allgather leaves */
+int ss_match_fold_strided_device(ss_ctx *ctx, const void *d_parts, int n_parts, int64_t part_stride_bytes, int n_query, int th,
+                                 int ratio_num, int ratio_den, void *d_idx, void *d_d1, void *d_d2);
+
+/* ---- the exchange step of configs 4 and 5 without PyTorch / RCCL ---------------------------------
+ * One process per GPU.  ss_xchg_create is collective: every rank calls it with the same world, max_bytes and rendezvous
+ * (the path of a Unix-domain socket rank 0 listens on while the hipIpc handles of the ranks' slabs are swapped); every rank
+ * then has every peer's slab mapped -- different GPUs of one node (xGMI) or the same GPU.  A message is ONE hop: each rank
+ * stores its block straight into every peer's slab and raises a flag there (csrc/ss_xchg.hip).
+ *
+ * ss_xchg_allgather: every rank contributes the same number of bytes, as up to 4 device segments laid back to back (each
+ * padded to 16 bytes); on return *d_gathered points at [world][*rank_stride] bytes of LOCAL device memory, rank r's
+ * block at r * *rank_stride, valid until the second-next message of this exchange.  ss_xchg_broadcast: d_buf of `root` ->
+ * d_buf of everybody (in place, like ncclBroadcast).  Both are asynchronous on ctx's stream: enqueue the consumers on the same
+ * stream.  Every rank must issue the same sequence of messages.  A peer that does not show up within the time limit ends
+ * the waiting kernel (it never hangs the GPU) and poisons the exchange: ss_xchg_status / the next call return SS_ERR_STATE.
+ * ss_xchg_destroy is collective too (a last flag-only message, so that nobody unmaps memory a peer still writes).
+ * The reference has nothing here: one camera, one TCP link (orbslam3_mono_networked.cc:387-388, application.ex:80). */
+typedef struct ss_xchg ss_xchg;
+int ss_xchg_create(int device_ordinal, int rank, int world, int64_t max_bytes, const char *rendezvous, int timeout_ms,
+                   ss_xchg **out);
+int ss_xchg_destroy(ss_xchg *x);
+/* x may be NULL: message of the last failed ss_xchg_create on this thread */
+const char *ss_xchg_last_error(const ss_xchg *x);
+int ss_xchg_status(ss_xchg *x);
+int ss_xchg_allgather(ss_xchg *x, ss_ctx *ctx, const void *const *d_segments, const int64_t *segment_bytes, int n_segments,
+                      const void **d_gathered, int64_t *rank_stride);
+int ss_xchg_broadcast(ss_xchg *x, ss_ctx *ctx, int root, void *d_buf, int64_t bytes);
 
 int ss_synchronize(ss_ctx *ctx);
 /* Orders the context's stream after everything enqueued so far on another stream of the same device

@@ -884,6 +884,22 @@ int ss_match_fold_device(ss_ctx *c, const void *d_parts, int n_parts, int n_quer
     return SS_OK;
 }
 
+int ss_match_fold_strided_device(ss_ctx *c, const void *d_parts, int n_parts, int64_t part_stride_bytes, int n_query, int th,
+                                 int ratio_num, int ratio_den, void *d_idx, void *d_d1, void *d_d2)
+{
+    if (!c) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n_parts < 1 || n_query < 0 || ratio_den <= 0 || ratio_num < 0 || part_stride_bytes % 8 != 0 || part_stride_bytes < (int64_t)n_query * 8)
+        return fail(c, SS_ERR_INVALID_ARG, "bad fold arguments");
+    if (n_query == 0) return SS_OK;
+    if (!d_parts || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL fold buffer");
+    stage_timer t(c, "match_fold", (int64_t)n_parts * n_query * 8 + (int64_t)n_query * 8);
+    ssk_match_fold_strided(c->stream, d_parts, part_stride_bytes, n_parts, n_query, th, ratio_num, ratio_den, (int32_t *)d_idx, (uint16_t *)d_d1,
+                           (uint16_t *)d_d2);
+    HIP_TRY(c, hipGetLastError());
+    return SS_OK;
+}
+
 int ss_wait_stream(ss_ctx *c, void *hip_stream)
 {
     if (!c) return SS_ERR_INVALID_ARG;

@@ -58,6 +58,8 @@ void ssk_pack_partial(hipStream_t s, const int32_t *idx, const uint16_t *d1, con
 /* cross-shard fold: parts [n_parts][nq] in ascending row order -> final outputs (k_match_merge's rule) */
 void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int th, int rnum, int rden, int32_t *idx,
                     uint16_t *d1, uint16_t *d2);
+void ssk_match_fold_strided(hipStream_t s, const void *parts, int64_t part_stride_bytes, int n_parts, int nq, int th, int rnum, int rden,
+                            int32_t *idx, uint16_t *d1, uint16_t *d2);
 /* the matrix-core matcher on descriptors already expanded to one FP4 value (+1 / -1) per bit (desc_x, SSK_X_ROW bytes per
  * row, written by ssk_orient_describe): batches of frames; frame strides in BYTES; multiples of 32 rows allocated */
 #define SSK_X_ROW 128

@@ -3129,6 +3129,31 @@ void ssk_match_fold(hipStream_t s, const void *parts, int n_parts, int nq, int t
                        nq, n_parts, th, rnum, rden, nq, idx, d1, d2);
 }
 
+/* the cross-shard fold on parts that sit part_stride_bytes apart (what ss_xchg_allgather leaves) */
+__global__ __launch_bounds__(256) void k_match_fold_strided(const uint8_t *__restrict__ parts, int64_t part_stride_bytes, int n_parts, int nq, int th,
+                                                            int rnum, int rden, int32_t *__restrict__ idx_out, uint16_t *__restrict__ d1_out,
+                                                            uint16_t *__restrict__ d2_out)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int d1 = 0xFFFF, d2 = 0xFFFF, j1 = -1;
+    for (int c = 0; c < n_parts; c++) {
+        const match_partial mp = ((const match_partial *)(parts + (size_t)c * part_stride_bytes))[qi];
+        merge_partial(d1, j1, d2, mp.d1, mp.j1, mp.d2);
+    }
+    const bool ok = j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
+    idx_out[qi] = ok ? j1 : -1;
+    d1_out[qi] = (uint16_t)d1;
+    d2_out[qi] = (uint16_t)d2;
+}
+
+void ssk_match_fold_strided(hipStream_t s, const void *parts, int64_t part_stride_bytes, int n_parts, int nq, int th, int rnum, int rden,
+                            int32_t *idx, uint16_t *d1, uint16_t *d2)
+{
+    hipLaunchKernelGGL(k_match_fold_strided, dim3((nq + 255) / 256), dim3(256), 0, s, (const uint8_t *)parts, part_stride_bytes, n_parts, nq, th,
+                       rnum, rden, idx, d1, d2);
+}
+
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n)
 {
     if (n < 0 || n > QT_MAX_ITEMS) return -1;

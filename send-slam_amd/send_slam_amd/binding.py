@@ -16,7 +16,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
 SS_MAX_LEVELS = 16
 EXPANDED_ROW_BYTES = 128  # one FP4 value (+1 / -1) per descriptor bit
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SS_OK = 0
 SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3, -4
@@ -30,7 +30,9 @@ EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy",
            "ss_match_pairs_device", "ss_expand_descriptors_device", "ss_match_expanded_device",
            "ss_match_partial_expanded_device", "ss_track_features", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
            "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
-           "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight"]
+           "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight",
+           "ss_match_fold_strided_device", "ss_xchg_create", "ss_xchg_destroy", "ss_xchg_last_error", "ss_xchg_status",
+           "ss_xchg_allgather", "ss_xchg_broadcast"]
 
 
 class OrbParams(C.Structure):
@@ -161,6 +163,16 @@ def load():
     lib.ss_match_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ss_wait_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ss_match_fold_strided_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ss_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.ss_xchg_destroy.argtypes = [C.c_void_p]
+    lib.ss_xchg_last_error.restype = C.c_char_p
+    lib.ss_xchg_last_error.argtypes = [C.c_void_p]
+    lib.ss_xchg_status.argtypes = [C.c_void_p]
+    lib.ss_xchg_allgather.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.ss_xchg_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     lib.ss_pipe_create.argtypes = [C.c_int, C.POINTER(OrbParams), C.POINTER(Camera), C.POINTER(PipeConfig),
                                    C.POINTER(C.c_void_p)]
     lib.ss_pipe_destroy.argtypes = [C.c_void_p]
@@ -353,6 +365,12 @@ class OrbContext:
         self._check(self._lib.ss_match_fold_device(self._h, C.c_void_p(d_parts), n_parts, nq, th, ratio_num, ratio_den,
                                                    C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)))
 
+    def match_fold_strided_device(self, d_parts: int, n_parts: int, part_stride_bytes: int, nq: int, d_idx: int, d_d1: int,
+                                  d_d2: int, th: int = 50, ratio_num: int = 9, ratio_den: int = 10):
+        """the fold on parts part_stride_bytes apart: the layout Exchange.allgather leaves"""
+        self._check(self._lib.ss_match_fold_strided_device(self._h, C.c_void_p(d_parts), n_parts, part_stride_bytes, nq, th, ratio_num,
+                                                           ratio_den, C.c_void_p(d_idx), C.c_void_p(d_d1), C.c_void_p(d_d2)))
+
     def wait_stream(self, hip_stream: int):
         """Orders this context's stream after everything enqueued so far on another stream of the device."""
         self._check(self._lib.ss_wait_stream(self._h, C.c_void_p(hip_stream)))
@@ -382,6 +400,58 @@ class OrbContext:
         out = np.empty(shape, dtype)
         n = self._check(self._lib.ss_debug_fetch(self._h, what, frame, level, out.ctypes.data, out.nbytes))
         return out.reshape(-1)[: n // out.itemsize]
+
+
+class Exchange:
+    """ss_xchg_*: the C ABI's own all-gather / broadcast between the ranks of one node (one process per GPU): every rank
+    stores its block straight into every peer's IPC-mapped slab and raises a flag there.  Creation and destruction are
+    collective; every rank issues the same sequence of messages; consumers of a gathered block are enqueued on the same
+    context's stream."""
+
+    def __init__(self, device: int, rank: int, world: int, max_bytes: int, rendezvous: str, timeout_ms: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.ss_xchg_create(int(device), int(rank), int(world), int(max_bytes), rendezvous.encode(), int(timeout_ms), C.byref(h))
+        if rc != SS_OK:
+            raise OrbError(rc, (self._lib.ss_xchg_last_error(None) or b"").decode())
+        self._h = h
+        self.rank, self.world = rank, world
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise OrbError(rc, (self._lib.ss_xchg_last_error(self._h) or b"").decode())
+        return rc
+
+    def allgather(self, ctx: "OrbContext", segments):
+        """segments: [(device pointer, bytes), ...] (<= 4), the same sizes on every rank.  Returns (base, stride): rank r's
+        block is at base + r * stride in LOCAL device memory, the segments back to back (each padded to 16 bytes); valid
+        until the second-next message."""
+        n = len(segments)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p, _ in segments])
+        sizes = (C.c_int64 * n)(*[int(b) for _, b in segments])
+        base, stride = C.c_void_p(), C.c_int64()
+        self._check(self._lib.ss_xchg_allgather(self._h, ctx._h, ptrs, sizes, n, C.byref(base), C.byref(stride)))
+        return base.value, stride.value
+
+    def broadcast(self, ctx: "OrbContext", root: int, d_buf: int, nbytes: int):
+        self._check(self._lib.ss_xchg_broadcast(self._h, ctx._h, int(root), C.c_void_p(d_buf), int(nbytes)))
+
+    def status(self):
+        """raises if a peer's message did not arrive in time (valid once the stream has been synchronised)"""
+        self._check(self._lib.ss_xchg_status(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ss_xchg_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Pipe:

@@ -129,12 +129,48 @@ def expand_database(ctx, db_slab: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, th: int = 50,
+def _local_partial(ctx, query, db_slab, slab_begin, part, db_expanded, n_db):
+    nq, dev = query.shape[0], query.device
+    if db_expanded is not None:
+        # the slab was expanded once (expand_database); the query is expanded per call (nq x 128 B)
+        nt = db_slab.shape[0] if n_db is None else n_db
+        qx = torch.empty((ctx.expanded_bytes(nq) // 128, 128), dtype=torch.uint8, device=dev)
+        ctx.expand_descriptors_device(query.data_ptr(), nq, qx.data_ptr())
+        ctx.match_partial_expanded_device(qx.data_ptr(), nq, db_expanded.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+    else:
+        nt = db_slab.shape[0]
+        ctx.match_partial_device(query.data_ptr(), nq, db_slab.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+
+
+def loop_closure_query_native(ctx, xchg, query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, th: int = 50,
                               ratio_num: int = 9, ratio_den: int = 10, src: int = 0, out=None, db_expanded=None, n_db=None):
+    """Config 5 with the C ABI's own exchange (binding.Exchange = ss_xchg_*): ss_xchg_broadcast of the query ->
+    ss_match_partial*_device -> ss_xchg_allgather of world x nq x 8 B -> ss_match_fold_strided_device on the gathered
+    records where they landed.  No torch.distributed, no RCCL; torch only holds the buffers.  `query` is overwritten with
+    rank `src`'s on every other rank (in place, like ncclBroadcast)."""
+    nq, dev = query.shape[0], query.device
+    with on_ctx_stream(ctx, dev):  # the two scratch tensors below are allocated and freed in the context's stream order
+        xchg.broadcast(ctx, src, query.data_ptr(), nq * 32)
+        part = torch.empty(nq, dtype=torch.int64, device=dev)
+        _local_partial(ctx, query, db_slab, slab_begin, part, db_expanded, n_db)
+        base, stride = xchg.allgather(ctx, [(part.data_ptr(), nq * 8)])
+        if out is None:
+            out = (torch.empty(nq, dtype=torch.int32, device=dev), torch.empty(nq, dtype=torch.int16, device=dev),
+                   torch.empty(nq, dtype=torch.int16, device=dev))
+        ctx.match_fold_strided_device(base, xchg.world, stride, nq, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                      th=th, ratio_num=ratio_num, ratio_den=ratio_den)
+    return out
+
+
+def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, slab_begin: int, th: int = 50,
+                              ratio_num: int = 9, ratio_den: int = 10, src: int = 0, out=None, db_expanded=None, n_db=None,
+                              xchg=None):
     """Config 5 on the GPUs, behind the C ABI: broadcast -> ss_match_partial_device -> all_gather of
     world x nq x 8 B -> ss_match_fold_device, all on the context's stream (no host synchronisation inside;
     the caller synchronises when it reads the result).  Returns device tensors (idx i32, d1 i16, d2 i16:
-    the 16-bit distances, 0xFFFF = none)."""
+    the 16-bit distances, 0xFFFF = none).  With `xchg` (binding.Exchange) the two collectives are the library's own."""
+    if xchg is not None:
+        return loop_closure_query_native(ctx, xchg, query, db_slab, slab_begin, th, ratio_num, ratio_den, src, out, db_expanded, n_db)
     world = dist.get_world_size() if dist.is_initialized() else 1
     nq, dev = query.shape[0], query.device
     with on_ctx_stream(ctx, dev):
@@ -146,15 +182,7 @@ def loop_closure_query_device(ctx, query: torch.Tensor, db_slab: torch.Tensor, s
             else:
                 dist.broadcast(query, src=src)
         part = torch.empty(nq, dtype=torch.int64, device=dev)  # nq x ss_match_part (8 B)
-        if db_expanded is not None:
-            # the slab was expanded once (expand_database); the query is expanded per call (nq x 128 B)
-            nt = db_slab.shape[0] if n_db is None else n_db
-            qx = torch.empty((ctx.expanded_bytes(nq) // 128, 128), dtype=torch.uint8, device=dev)
-            ctx.expand_descriptors_device(query.data_ptr(), nq, qx.data_ptr())
-            ctx.match_partial_expanded_device(qx.data_ptr(), nq, db_expanded.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
-        else:
-            nt = db_slab.shape[0]
-            ctx.match_partial_device(query.data_ptr(), nq, db_slab.data_ptr() if nt else 0, nt, slab_begin, part.data_ptr())
+        _local_partial(ctx, query, db_slab, slab_begin, part, db_expanded, n_db)
         if world > 1:
             if dist.get_backend() == "gloo":
                 ctx.synchronize()
