@@ -16,7 +16,7 @@ weak scaling, value = frames all ranks processed / max-over-ranks time.
     python bench.py --gpus N --workload loop_closure [--exchange ...]      config 5
 
 Timing: R rounds of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced
-over the ranks; R is chosen from the first round so that the rounds together time >= 0.5 s whatever K is (at least 3).
+over the ranks; rounds are added until they together time >= 0.5 s whatever K is (at least 3 rounds).
 value = units all ranks processed in a round / the MEDIAN round's time; value_spread = min / median / max over the rounds.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -210,10 +210,8 @@ MIN_REGION_S = 0.5  # whatever --steps is, the rounds together time at least thi
 
 def timed_rounds(run_steps, steps, drain, world, dev, backend, max_rounds=400):
     """R rounds of EXACTLY `steps` steps.  Every round is bracketed by barrier + torch.cuda.synchronize() on both sides and
-    its time is the MAX over ranks; R comes from the first round (itself a timed round, after the warm-up) so that the
-    rounds together last >= MIN_REGION_S, at least 3.  The max-reduced time is the same number on every rank, so every
-    rank computes the same R.  Returns the list of round times in seconds."""
-    import math
+    its time is the MAX over ranks; rounds are added until they together last >= MIN_REGION_S, at least 3.  Returns the
+    list of round times in seconds."""
     import torch
     import torch.distributed as dist
     d = use_dist(world)
@@ -229,12 +227,16 @@ def timed_rounds(run_steps, steps, drain, world, dev, backend, max_rounds=400):
         if d:
             dist.barrier()
         return max_over_ranks(time.perf_counter() - t0, world, dev, backend)
-    times = [one()]
-    rounds = min(max_rounds, max(3, int(math.ceil(MIN_REGION_S / max(times[0], 1e-6)))))
-    if os.environ.get("SENDSLAM_BENCH_ROUNDS"):
-        rounds = max(1, int(os.environ["SENDSLAM_BENCH_ROUNDS"]))
-    for _ in range(rounds - 1):
+    # every time in `times` is max-reduced, so every rank sees the same numbers and stops after the same round
+    fixed = int(os.environ.get("SENDSLAM_BENCH_ROUNDS", "0"))
+    times = []
+    while len(times) < max_rounds:
         times.append(one())
+        if fixed:
+            if len(times) >= fixed:
+                break
+        elif len(times) >= 3 and sum(times) >= MIN_REGION_S:
+            break
     return times
 
 
