@@ -88,6 +88,8 @@ struct ss_ctx {
     size_t match_partial_bytes = 0;
     uint8_t *d_mq = nullptr, *d_mt = nullptr, *d_mout = nullptr, *d_part_tmp = nullptr;
     size_t d_mq_bytes = 0, d_mt_bytes = 0, d_mout_bytes = 0, d_part_tmp_bytes = 0;
+    uint8_t *d_qx = nullptr, *d_tx = nullptr; /* caller descriptors expanded to the matrix-core matcher's operand rows */
+    size_t d_qx_bytes = 0, d_tx_bytes = 0;
 
     /* host results of ss_extract */
     std::vector<ss_keypoint> h_kps;
@@ -100,6 +102,8 @@ struct ss_ctx {
     /* ss_track: descriptors of the initialisation reference / the previous frame, host geometry */
     uint8_t *d_ref_desc = nullptr, *d_prev_desc = nullptr;
     size_t d_ref_desc_bytes = 0, d_prev_desc_bytes = 0;
+    uint8_t *d_ref_desc_x = nullptr, *d_prev_desc_x = nullptr; /* the same rows as matrix-core operands (128 B each) */
+    size_t d_ref_desc_x_bytes = 0, d_prev_desc_x_bytes = 0;
     sst_tracker tracker;
     std::vector<float> h_xy;
     std::vector<int32_t> h_oct, h_midx;
@@ -464,8 +468,12 @@ int ss_destroy(ss_ctx *c)
     dev_free(c->d_mt);
     dev_free(c->d_mout);
     dev_free(c->d_part_tmp);
+    dev_free(c->d_qx);
+    dev_free(c->d_tx);
     dev_free(c->d_ref_desc);
     dev_free(c->d_prev_desc);
+    dev_free(c->d_ref_desc_x);
+    dev_free(c->d_prev_desc_x);
     (void)hipStreamDestroy(c->stream);
     delete c;
     return SS_OK;
@@ -614,6 +622,22 @@ int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_t
             return SS_OK;
         }
     }
+    if (n_query >= SSK_MATCH_MFMA_MIN_QUERIES && n_train > 0 && !c->no_desc_x) {
+        /* ONE matrix-core matcher for every entry point: the caller's packed rows are expanded to its operand format
+         * (k_expand_desc: 32 -> 128 bytes per row) and k_match_mfma_x runs on them.  SENDSLAM_MATCH_PACKED=1 keeps round 1's
+         * k_match_mfma, which expands every tile in every query block through an LDS table. */
+        const bool same = d_train == d_query && n_train == n_query;
+        int rc = grow(c, c->d_qx, c->d_qx_bytes, (size_t)SS_EXPANDED_BYTES(n_query));
+        if (rc == SS_OK && !same) rc = grow(c, c->d_tx, c->d_tx_bytes, (size_t)SS_EXPANDED_BYTES(n_train));
+        if (rc != SS_OK) return rc;
+        {
+            stage_timer t(c, "expand", ((int64_t)n_query + (same ? 0 : n_train)) * (32 + SSK_X_ROW));
+            ssk_expand_desc(c->stream, d_query, n_query, c->d_qx);
+            if (!same) ssk_expand_desc(c->stream, d_train, n_train, c->d_tx);
+        }
+        return ss_match_expanded_device(c, c->d_qx, n_query, same ? c->d_qx : c->d_tx, n_train, th, ratio_num, ratio_den, exclude_self, d_idx,
+                                        d_d1, d_d2);
+    }
     int chunk_len = 4;
     const int n_chunks = ssk_match_chunks(n_query, std::max(n_train, 1), 1, &chunk_len);
     if (n_chunks > 1) {
@@ -708,6 +732,36 @@ int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query,
     if (n_frames < 0 || rows_per_frame < 1 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
     if (n_frames == 0) return SS_OK;
     if (!d_query || !d_n_query || !d_train || !d_n_train || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
+    if (rows_per_frame >= SSK_MATCH_MFMA_MIN_QUERIES && !c->no_desc_x) {
+        /* both sides expanded frame by frame ([n_frames][rows rounded up to 32][128 B]), then the batch matcher of the metric
+         * path with per-frame counts on both sides */
+        const int rows_alloc = (rows_per_frame + 31) & ~31;
+        const size_t xb = (size_t)n_frames * rows_alloc * SSK_X_ROW;
+        int rc = grow(c, c->d_qx, c->d_qx_bytes, xb);
+        if (rc == SS_OK) rc = grow(c, c->d_tx, c->d_tx_bytes, xb);
+        if (rc != SS_OK) return rc;
+        const int q_groups = ((rows_per_frame + 127) / 128) * n_frames;
+        int want = std::max(1, std::min((3200 + q_groups / 2) / q_groups, (rows_per_frame + 255) / 256));
+        const int x_chunk = ((rows_per_frame + want - 1) / want + 31) & ~31;
+        const int x_chunks = (rows_per_frame + x_chunk - 1) / x_chunk;
+        if (x_chunks > 1) {
+            rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_frames * x_chunks * rows_per_frame * SSK_MATCH_PARTIAL_BYTES);
+            if (rc != SS_OK) return rc;
+        }
+        {
+            stage_timer t(c, "expand", (int64_t)2 * n_frames * rows_per_frame * (32 + SSK_X_ROW));
+            ssk_expand_desc_frames(c->stream, d_query, rows_per_frame, n_frames, c->d_qx);
+            ssk_expand_desc_frames(c->stream, d_train, rows_per_frame, n_frames, c->d_tx);
+        }
+        {
+            stage_timer t(c, "match", (int64_t)n_frames * rows_per_frame * (32 * 2 + 8));
+            ssk_match_x(c->stream, c->d_qx, c->d_tx, (const int32_t *)d_n_query, (const int32_t *)d_n_train, 0, 0, (int64_t)rows_alloc * SSK_X_ROW,
+                        (int64_t)rows_alloc * SSK_X_ROW, 0, x_chunk, x_chunks, 0, th, ratio_num, ratio_den, rows_per_frame, c->match_partial,
+                        (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n_frames);
+        }
+        HIP_TRY(c, hipGetLastError());
+        return SS_OK;
+    }
     int chunk_len = 4;
     const int n_chunks = ssk_match_chunks(rows_per_frame, rows_per_frame, n_frames, &chunk_len);
     if (n_chunks > 1) {
@@ -726,9 +780,19 @@ int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query,
 
 /* the pose half of the frame branch: device match against the initial / previous frame's descriptors, then the host
  * geometry (csrc/ss_track.cpp).  d_desc: n rows of 32 bytes in device memory, written on c->stream or complete. */
-static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t *d_desc, const ss_keypoint *kps, int n,
-                      ss_pose *out)
+static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t *d_desc, const uint8_t *d_desc_x, const ss_keypoint *kps,
+                      int n, ss_pose *out)
 {
+    /* d_desc_x: the same n rows already expanded (the extraction's desc_x), or NULL: expanded here when the matrix-core matcher
+     * is going to read them (as the query now, or as the next frames' train set) */
+    const bool use_x = !c->no_desc_x && n > 0;
+    if (use_x && !d_desc_x) {
+        int rcx = grow(c, c->d_qx, c->d_qx_bytes, (size_t)SS_EXPANDED_BYTES(n));
+        if (rcx != SS_OK) return rcx;
+        stage_timer t(c, "expand", (int64_t)n * (32 + SSK_X_ROW));
+        ssk_expand_desc(c->stream, d_desc, n, c->d_qx);
+        d_desc_x = c->d_qx;
+    }
     sst_tracker &tr = c->tracker;
     tr.cam = sst_camera{c->cam.fx, c->cam.fy, c->cam.cx, c->cam.cy, c->cam.k1, c->cam.k2, c->cam.p1, c->cam.p2};
     tr.scale_factor = c->params.scale_factor;
@@ -745,11 +809,15 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
     const int want = tr.want_match();
     if (want != SST_MATCH_NONE && n > 0) {
         const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : c->d_prev_desc;
+        const uint8_t *train_x = want == SST_MATCH_REF ? c->d_ref_desc_x : c->d_prev_desc_x;
         rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n * 8);
         if (rc != SS_OK) return rc;
         int32_t *di = (int32_t *)c->d_mout;
         uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
-        rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+        if (use_x && train_x && n >= SSK_MATCH_MFMA_MIN_QUERIES && tr.n_train() > 0) /* both operands are expanded already */
+            rc = ss_match_expanded_device(c, d_desc_x, n, train_x, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+        else
+            rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
         if (rc != SS_OK) return rc;
         HIP_TRY(c, hipMemcpyAsync(c->h_midx.data(), di, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->h_md1.data(), dd1, (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
@@ -763,6 +831,13 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
         rc = grow(c, dst, dst_bytes, (size_t)n * SS_DESC_BYTES);
         if (rc != SS_OK) return rc;
         HIP_TRY(c, hipMemcpyAsync(dst, d_desc, (size_t)n * SS_DESC_BYTES, hipMemcpyDeviceToDevice, c->stream));
+        if (use_x) {
+            uint8_t *&dst_x = keep == SST_KEEP_AS_REF ? c->d_ref_desc_x : c->d_prev_desc_x;
+            size_t &dst_x_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_x_bytes : c->d_prev_desc_x_bytes;
+            rc = grow(c, dst_x, dst_x_bytes, (size_t)SS_EXPANDED_BYTES(n));
+            if (rc != SS_OK) return rc;
+            HIP_TRY(c, hipMemcpyAsync(dst_x, d_desc_x, (size_t)SS_EXPANDED_BYTES(n), hipMemcpyDeviceToDevice, c->stream));
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     out->tracking_state = po.state;
@@ -786,7 +861,7 @@ int ss_track(ss_ctx *c, int camera_id, const uint8_t *pix, int width, int height
     int rc = ss_extract(c, camera_id, pix, width, height, channels, row_stride, timestamp, &res);
     if (rc != SS_OK) return rc;
     /* this frame's descriptors are still in HBM (frame 0 of the batch arrays) */
-    return track_step(c, camera_id, timestamp, c->desc, res.keypoints, res.n_keypoints, out);
+    return track_step(c, camera_id, timestamp, c->desc, c->desc_x, res.keypoints, res.n_keypoints, out);
 }
 
 int ss_track_features(ss_ctx *c, int camera_id, double timestamp, const void *d_descriptors, const ss_keypoint *keypoints,
@@ -797,7 +872,7 @@ int ss_track_features(ss_ctx *c, int camera_id, double timestamp, const void *d_
     if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
     if (camera_id == 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing camera identifier.");
     if (n_keypoints > 0 && (!d_descriptors || !keypoints)) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features: NULL feature arrays");
-    return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, keypoints, n_keypoints, out);
+    return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, nullptr, keypoints, n_keypoints, out);
 }
 
 int ss_expand_descriptors_device(ss_ctx *c, const void *d_packed, int n, void *d_expanded)

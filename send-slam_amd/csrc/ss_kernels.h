@@ -69,6 +69,8 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
                  uint16_t *d1, uint16_t *d2, int n_frames);
 /* packed 32-B descriptors -> expanded SSK_X_ROW-byte rows; `out` holds n rounded up to 32 rows */
 void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out);
+/* [n_frames][rows][32] packed -> [n_frames][rows rounded up to 32][SSK_X_ROW] */
+void ssk_expand_desc_frames(hipStream_t s, const void *packed, int rows, int n_frames, void *out);
 /* one expanded query set against one expanded train set (any size): chunk plan + launch (+ merge of the chunk partials) */
 int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len);
 void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uint8_t *train_x, int nt, int chunk_len, int n_chunks,

@@ -2670,10 +2670,14 @@ __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__rest
 /* packed descriptors (32 B) -> the matrix-core matcher's operand rows (SS_X_ROW bytes, fp4_of_4bits), the same format
  * k_orient_describe writes for the frames of a batch.  One wave per row, one coalesced 128-byte store; rows n .. n_alloc - 1
  * (n_alloc = n rounded up to the 32-row tile) are zero-filled (FP4 zeros: they contribute 0 and are masked anyway). */
-__global__ __launch_bounds__(256) void k_expand_desc(const uint32_t *__restrict__ packed, int n, int n_alloc, uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void k_expand_desc(const uint32_t *__restrict__ packed, int n, int n_alloc, uint8_t *__restrict__ out,
+                                                     int64_t src_frame_words, int64_t dst_frame_bytes)
 {
+    /* blockIdx.y = frame of a batch ([frames][n][32] packed -> [frames][n_alloc][SS_X_ROW]); a single set has one frame */
     const int row = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = lane_id();
     if (row >= n_alloc) return;
+    packed += (size_t)blockIdx.y * src_frame_words;
+    out += (size_t)blockIdx.y * dst_frame_bytes;
     uint32_t v = 0;
     if (row < n) {
         const uint32_t w = packed[(size_t)row * 8 + (lane >> 3)];
@@ -3013,7 +3017,18 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
 void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out)
 {
     const int n_alloc = (n + MM_TILE - 1) & ~(MM_TILE - 1);
-    if (n_alloc > 0) hipLaunchKernelGGL(k_expand_desc, dim3((n_alloc + 3) / 4), dim3(256), 0, s, (const uint32_t *)packed, n, n_alloc, (uint8_t *)out);
+    if (n_alloc > 0)
+        hipLaunchKernelGGL(k_expand_desc, dim3((n_alloc + 3) / 4), dim3(256), 0, s, (const uint32_t *)packed, n, n_alloc, (uint8_t *)out, (int64_t)0,
+                           (int64_t)0);
+}
+
+/* [n_frames][rows][32] packed -> [n_frames][rows rounded up to 32][SSK_X_ROW] */
+void ssk_expand_desc_frames(hipStream_t s, const void *packed, int rows, int n_frames, void *out)
+{
+    const int n_alloc = (rows + MM_TILE - 1) & ~(MM_TILE - 1);
+    if (n_alloc > 0 && n_frames > 0)
+        hipLaunchKernelGGL(k_expand_desc, dim3((n_alloc + 3) / 4, n_frames), dim3(256), 0, s, (const uint32_t *)packed, rows, n_alloc, (uint8_t *)out,
+                           (int64_t)rows * 8, (int64_t)n_alloc * SS_X_ROW);
 }
 
 /* one query set against one (large) train set, both expanded: chunks of <= 8192 rows (the key's row field), the 16
