@@ -393,6 +393,9 @@ template <typename T> int grow(ss_ctx *c, T *&p, size_t &have, size_t want)
 
 } // namespace
 
+static int match_expanded(ss_ctx *c, const void *d_query_x, int n_query, const void *d_train_x, int n_train, int th, int ratio_num,
+                          int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2, const uint8_t *q_packed, const uint8_t *t_packed);
+
 extern "C" {
 
 int ss_abi_version(void) { return SS_ABI_VERSION; }
@@ -635,8 +638,8 @@ int ss_match_device(ss_ctx *c, const void *d_query, int n_query, const void *d_t
             ssk_expand_desc(c->stream, d_query, n_query, c->d_qx);
             if (!same) ssk_expand_desc(c->stream, d_train, n_train, c->d_tx);
         }
-        return ss_match_expanded_device(c, c->d_qx, n_query, same ? c->d_qx : c->d_tx, n_train, th, ratio_num, ratio_den, exclude_self, d_idx,
-                                        d_d1, d_d2);
+        return match_expanded(c, c->d_qx, n_query, same ? c->d_qx : c->d_tx, n_train, th, ratio_num, ratio_den, exclude_self, d_idx, d_d1, d_d2,
+                              (const uint8_t *)d_query, (const uint8_t *)d_train);
     }
     int chunk_len = 4;
     const int n_chunks = ssk_match_chunks(n_query, std::max(n_train, 1), 1, &chunk_len);
@@ -688,17 +691,8 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
     const int n = c->last_n_frames, kcap = c->hg.kcap;
     int chunk_len = 4;
     int n_chunks = ssk_match_chunks(kcap, kcap, n, &chunk_len);
-    if (c->desc_x) {
-        /* k_match_mfma_x: ~3200 blocks of 128 queries x one train chunk of >= 8 tiles (measured at 64 x 2112 rows: 1 chunk
-         * 0.062 ms, 2 -> 0.059, 3 -> 0.057, 4 -> 0.058); SENDSLAM_MX_CHUNKS overrides (experiments) */
-        const int q_groups = ((kcap + 127) / 128) * n;
-        int want = (3200 + q_groups / 2) / q_groups;
-        if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) want = atoi(e);
-        want = std::max(1, std::min(want, (kcap + 255) / 256));
-        chunk_len = ((kcap + want - 1) / want + 31) & ~31;
-        n_chunks = (kcap + chunk_len - 1) / chunk_len;
-    }
-    if (n_chunks > 1) {
+    if (c->desc_x) n_chunks = ssk_match_x_batch_chunks(kcap, kcap, n, &chunk_len);
+    if (n_chunks > 1 || c->desc_x) { /* the matrix-core matcher always writes partials: its second launch finishes them */
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n * n_chunks * kcap * SSK_MATCH_PARTIAL_BYTES);
         if (rc != SS_OK) return rc;
     }
@@ -713,7 +707,8 @@ int ss_match_batch_device(ss_ctx *c, int mode, int th, int ratio_num, int ratio_
         if (c->desc_x)
             ssk_match_x(c->stream, c->desc_x, c->desc_x, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * SSK_X_ROW, (int64_t)kcap * SSK_X_ROW,
                         mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
-                        c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n);
+                        c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n, c->desc, c->desc, (int64_t)kcap * SS_DESC_BYTES,
+                        (int64_t)kcap * SS_DESC_BYTES);
         else
             ssk_match(c->stream, c->desc, c->desc, c->n_kp, c->n_kp, 0, 0, (int64_t)kcap * 8, (int64_t)kcap * 8,
                       mode == 0 ? 0 : -1, chunk_len, n_chunks, mode == 0 ? 1 : 2, th, ratio_num, ratio_den, kcap,
@@ -740,14 +735,10 @@ int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query,
         int rc = grow(c, c->d_qx, c->d_qx_bytes, xb);
         if (rc == SS_OK) rc = grow(c, c->d_tx, c->d_tx_bytes, xb);
         if (rc != SS_OK) return rc;
-        const int q_groups = ((rows_per_frame + 127) / 128) * n_frames;
-        int want = std::max(1, std::min((3200 + q_groups / 2) / q_groups, (rows_per_frame + 255) / 256));
-        const int x_chunk = ((rows_per_frame + want - 1) / want + 31) & ~31;
-        const int x_chunks = (rows_per_frame + x_chunk - 1) / x_chunk;
-        if (x_chunks > 1) {
-            rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_frames * x_chunks * rows_per_frame * SSK_MATCH_PARTIAL_BYTES);
-            if (rc != SS_OK) return rc;
-        }
+        int x_chunk = 32;
+        const int x_chunks = ssk_match_x_batch_chunks(rows_per_frame, rows_per_frame, n_frames, &x_chunk);
+        rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_frames * x_chunks * rows_per_frame * SSK_MATCH_PARTIAL_BYTES);
+        if (rc != SS_OK) return rc;
         {
             stage_timer t(c, "expand", (int64_t)2 * n_frames * rows_per_frame * (32 + SSK_X_ROW));
             ssk_expand_desc_frames(c->stream, d_query, rows_per_frame, n_frames, c->d_qx);
@@ -757,7 +748,8 @@ int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query,
             stage_timer t(c, "match", (int64_t)n_frames * rows_per_frame * (32 * 2 + 8));
             ssk_match_x(c->stream, c->d_qx, c->d_tx, (const int32_t *)d_n_query, (const int32_t *)d_n_train, 0, 0, (int64_t)rows_alloc * SSK_X_ROW,
                         (int64_t)rows_alloc * SSK_X_ROW, 0, x_chunk, x_chunks, 0, th, ratio_num, ratio_den, rows_per_frame, c->match_partial,
-                        (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n_frames);
+                        (int32_t *)d_idx, (uint16_t *)d_d1, (uint16_t *)d_d2, n_frames, (const uint8_t *)d_query, (const uint8_t *)d_train,
+                        (int64_t)rows_per_frame * SS_DESC_BYTES, (int64_t)rows_per_frame * SS_DESC_BYTES);
         }
         HIP_TRY(c, hipGetLastError());
         return SS_OK;
@@ -815,7 +807,7 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
         int32_t *di = (int32_t *)c->d_mout;
         uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
         if (use_x && train_x && n >= SSK_MATCH_MFMA_MIN_QUERIES && tr.n_train() > 0) /* both operands are expanded already */
-            rc = ss_match_expanded_device(c, d_desc_x, n, train_x, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+            rc = match_expanded(c, d_desc_x, n, train_x, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2, d_desc, train);
         else
             rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
         if (rc != SS_OK) return rc;
@@ -891,6 +883,13 @@ int ss_expand_descriptors_device(ss_ctx *c, const void *d_packed, int n, void *d
 int ss_match_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, const void *d_train_x, int n_train, int th, int ratio_num,
                              int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2)
 {
+    return match_expanded(c, d_query_x, n_query, d_train_x, n_train, th, ratio_num, ratio_den, exclude_self, d_idx, d_d1, d_d2, nullptr, nullptr);
+}
+
+/* q_packed / t_packed: the same rows as packed descriptors when the caller has them (the finishing launch reads those) */
+static int match_expanded(ss_ctx *c, const void *d_query_x, int n_query, const void *d_train_x, int n_train, int th, int ratio_num,
+                          int ratio_den, int exclude_self, void *d_idx, void *d_d1, void *d_d2, const uint8_t *q_packed, const uint8_t *t_packed)
+{
     if (!c) return SS_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     if (n_query < 0 || n_train < 0 || ratio_den <= 0 || ratio_num < 0) return fail(c, SS_ERR_INVALID_ARG, "bad match arguments");
@@ -898,7 +897,7 @@ int ss_match_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, cons
     if (!d_query_x || (!d_train_x && n_train > 0) || !d_idx || !d_d1 || !d_d2) return fail(c, SS_ERR_INVALID_ARG, "NULL match buffer");
     int chunk_len = 32;
     const int n_chunks = ssk_match_x_chunks(n_query, std::max(n_train, 1), &chunk_len);
-    if (n_chunks > 1) {
+    {
         int rc = grow(c, c->match_partial, c->match_partial_bytes, (size_t)n_chunks * n_query * SSK_MATCH_PARTIAL_BYTES);
         if (rc != SS_OK) return rc;
     }
@@ -906,7 +905,7 @@ int ss_match_expanded_device(ss_ctx *c, const void *d_query_x, int n_query, cons
         stage_timer t(c, "match", (int64_t)n_query * SSK_X_ROW + (int64_t)n_train * SSK_X_ROW + (int64_t)n_query * 8);
         ssk_match_x_single(c->stream, (const uint8_t *)d_query_x, n_query, (const uint8_t *)(d_train_x ? d_train_x : d_query_x), n_train,
                            chunk_len, n_chunks, exclude_self, th, ratio_num, ratio_den, c->match_partial, (int32_t *)d_idx, (uint16_t *)d_d1,
-                           (uint16_t *)d_d2);
+                           (uint16_t *)d_d2, q_packed, t_packed);
     }
     HIP_TRY(c, hipGetLastError());
     return SS_OK;

@@ -66,15 +66,21 @@ void ssk_match_fold_strided(hipStream_t s, const void *parts, int64_t part_strid
 void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
                  int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
                  int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
-                 uint16_t *d1, uint16_t *d2, int n_frames);
+                 uint16_t *d1, uint16_t *d2, int n_frames, const uint8_t *query_p = nullptr, const uint8_t *train_p = nullptr,
+                 int64_t qp_frame_stride = 0, int64_t tp_frame_stride = 0);
+/* (query_p / train_p: the same rows as packed 32-byte descriptors where the caller has them, frame strides in bytes: the second
+ * launch, which recomputes 15 distances per query, then reads a quarter of the bytes) */
 /* packed 32-B descriptors -> expanded SSK_X_ROW-byte rows; `out` holds n rounded up to 32 rows */
 void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out);
 /* [n_frames][rows][32] packed -> [n_frames][rows rounded up to 32][SSK_X_ROW] */
 void ssk_expand_desc_frames(hipStream_t s, const void *packed, int rows, int n_frames, void *out);
 /* one expanded query set against one expanded train set (any size): chunk plan + launch (+ merge of the chunk partials) */
 int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len);
+/* chunk plan of a batch of frames (rows_q query rows against rows_t train rows per frame) */
+int ssk_match_x_batch_chunks(int rows_q, int rows_t, int n_frames, int *chunk_len);
 void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uint8_t *train_x, int nt, int chunk_len, int n_chunks,
-                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2);
+                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2,
+                        const uint8_t *query_p = nullptr, const uint8_t *train_p = nullptr);
 /* test hook: run the device std::sort restatement on n <= 2048 items (size << 32 | UL.x << 20 | id) */
 int ssk_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 #define SSK_MATCH_PARTIAL_BYTES 8

@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "ss_constants.h"
@@ -2429,25 +2430,33 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
 
 /* ------------------------------------------------------------------------------------ */
 /* K7 on the matrix cores, operands already expanded (k_orient_describe's desc_x / k_expand_desc: one FP4 value per           */
-/* descriptor bit, +1 / -1, 128 bytes per row).  Same contraction, same rule, same grid contract and outputs as                */
-/* k_match_mfma, but the loop neither expands nor forms keys, and the contraction runs at the FP4 rate:                         */
+/* descriptor bit, +1 / -1, 128 bytes per row).                                                                                  */
 /* * v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands takes the time of the i8 32x32x32 instruction for twice the K           */
-/*   (profiles/tools/fp4_probe.hip: 17.6 ns against 18.1 ns per instruction and SIMD): 4 instructions per 32-row tile           */
-/*   instead of 8.  The E8M0 block scale 2^12 on the train operand makes every product +-4096, so the 256-term dot product       */
-/*   of a row with a sign-flipped row is 8192 * hamming - 2^20, exact in f32 (|values| < 2^22).                                  */
+/*   (profiles/tools/fp4_probe.hip): 4 instructions per 32 x 32 tile of pairs.  The E8M0 block scale 2^12 on the train           */
+/*   operand makes every product +-4096, so the 256-term dot product of a row with a sign-flipped row is                         */
+/*   8192 * hamming - 2^20, exact in f32 (|values| < 2^22).                                                                      */
+/* * a wave owns TWO 32-query B tiles (64 queries, a block 256): every train fragment read from LDS feeds two MFMAs and a        */
+/*   train tile is copied into LDS once per 256 queries.  Round 2 had one tile per wave: its L2 -> LDS stream (32 B per           */
+/*   clock and CU at the matrix rate) sat at what the L2 delivers.                                                               */
 /* * a 32-row train tile is 4 KB of consecutive bytes that the block copies global -> LDS by LDS-DMA                            */
-/*   (global_load_lds_dwordx4: no VGPR, no VALU, no lookup table) MX_NBUF - 1 phases ahead of the MFMAs that read it; the        */
-/*   query fragments are four 16-byte global loads per lane, sign-flipped once (x ^ 0x88..: +1 <-> -1).  LDS image: rows at a    */
+/*   (global_load_lds_dwordx4: no VGPR, no VALU) MX_NBUF - 1 phases ahead of the MFMAs that read it.  LDS image: rows at a       */
 /*   144-byte pitch (ds_read_b128 of 32 rows x 16 bytes is conflict-free there); a DMA instruction writes 64 consecutive         */
 /*   16-byte units, so each lane's SOURCE address places the padding (unit u -> row u / 9, piece u % 9; piece 8 = pad).          */
-/* * the accumulator INPUT of a tile is 2^20 + the row's index in the chunk: the MFMA result IS the key 8192 * hamming + row     */
-/*   as a non-negative float, whose bit pattern orders like the value (smallest key = best distance at the lowest row, second    */
-/*   smallest carries the second-best distance).  The row-index vector advances by 32 per tile with one extra MFMA               */
-/*   (4.0 x 4.0 x 2^1 in k-slot 0: +32 everywhere) instead of 16 VALU additions per lane: the matrix pipe has the room, the       */
-/*   VALU does not.  Selection: v_med3_u32 + v_min_u32 per pair, nothing else.                                                    */
-/* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their accumulator input, in the          */
-/*   few tiles that contain such rows (wave-uniform test).                                                                        */
-/* Chunks are <= 8192 rows (13-bit row field).                                                                                    */
+/* * the key is the accumulator: its INPUT is the constant 2^20 + 8160 + row-in-tile, so the MFMA result is                      */
+/*   8192 * hamming + 8160 + row as a non-negative float whose bit pattern orders like its value.  Instead of advancing the     */
+/*   row field of the NEW keys per tile (round 2: a fifth MFMA), the two RUNNING keys of a lane lose 32 per tile (two            */
+/*   v_sub_f32): older rows then always carry the smaller field, which is all the ordering needs; the field is decoded at        */
+/*   the end.  Chunks are <= 8192 rows (13-bit field).                                                                            */
+/* * selection by GROUPS.  A lane's 16 accumulator registers are, for one query, four aligned blocks of four consecutive        */
+/*   train rows.  The lane reduces each block to its minimum (v_min3_u32 + v_min_u32) and keeps the two smallest block minima     */
+/*   (v_med3_u32 + v_min_u32 per block): 16 vector instructions per tile and query tile where the pairwise best / second-best      */
+/*   took 32 -- round 2's kernel was bound by vector ISSUE (every MFMA also holds the issue port for 8 cycles), not by the         */
+/*   matrix pipe.  What is kept is exact for the best (distance, row) and for the second best OVER THE OTHER BLOCKS; the second    */
+/*   best inside the best row's own block -- three rows, one 128-byte line of packed descriptors -- is recomputed by               */
+/*   k_match_finish_x after the chunk partials have been folded (second = min(second over the other blocks, best of those          */
+/*   three)).  Nothing is approximated.                                                                                            */
+/* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their keys, in the few tiles that         */
+/*   contain such rows (wave-uniform test).                                                                                       */
 /* ------------------------------------------------------------------------------------ */
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -2456,25 +2465,30 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define MX_DMAS ((MX_UNITS + 63) / 64)           /* 5 DMA instructions per tile (the last one half used) */
 #define MX_BUF (MX_DMAS * 1024)
 #define MX_ROW_BITS 13
+#define MX_FIELD0 8160         /* row field of a new key: 8160 + row in tile; a running key loses 32 per later tile */
 #define MX_NONE_F 268435456.0f /* 2^28 */
+#define MX_INIT_KEY 0x4E800000u /* 2^30 as a float: "nothing seen"; 2^30 - 32 rounds back to 2^30 */
 #define MX_FMT_FP4 4
 #define MX_SCALE_ONE 127       /* E8M0: 2^(x - 127) */
+#define MX_QT 2                /* 32-query tiles per wave */
+#define MX_QBLOCK (32 * MX_QT * 4)
 #ifndef MX_NBUF
-#define MX_NBUF 3 /* LDS ring: the DMA of a tile is issued MX_NBUF - 1 phases before the MFMAs that read it */
+#define MX_NBUF 4 /* LDS ring: the DMA of a tile is issued MX_NBUF - 1 steps before the MFMAs that read it, MX_NBUF - 2 before its fragments are read */
 #endif
 #ifndef MX_WAVES_PER_SIMD
-#define MX_WAVES_PER_SIMD 5
+#define MX_WAVES_PER_SIMD 2
 #endif
 
-__device__ __forceinline__ void mx_select(const v16f &acc, uint32_t (&k1)[2], uint32_t (&k2)[2])
+/* a lane's 16 keys are four GROUPS of four consecutive train rows (registers 4 g .. 4 g + 3 = rows 8 g + 4 half .. + 3 of the
+ * tile: the aligned block of four rows): the minimum of each group, then the two smallest group minima seen so far */
+__device__ __forceinline__ void mx_select(const v16f &acc, uint32_t &k1, uint32_t &k2)
 {
-    /* two independent (best, second) chains per lane; they merge once, at the end */
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const uint32_t key = __float_as_uint(acc[r]);
-        const int c = r & 1;
-        k2[c] = min(max(k1[c], k2[c]), max(min(k1[c], k2[c]), key));
-        k1[c] = min(k1[c], key);
+    for (int g = 0; g < 4; g++) {
+        const uint32_t m = min(min(min(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1])), __float_as_uint(acc[4 * g + 2])),
+                               __float_as_uint(acc[4 * g + 3])); /* v_min3_u32 + v_min_u32 */
+        k2 = min(max(k1, k2), max(min(k1, k2), m));              /* v_med3_u32 */
+        k1 = min(k1, m);
     }
 }
 
@@ -2488,15 +2502,13 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
                                                        const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                        int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                        int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
-                                                       int th, int rnum, int rden, int out_stride,
-                                                       match_partial *__restrict__ partial, int32_t *__restrict__ idx_out,
-                                                       uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+                                                       int out_stride, match_partial *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[MX_NBUF][MX_BUF];
     /* 1-D grid, XCD-aware: every XCD gets a contiguous run of (frame, chunk, query block) triples, so the blocks that
      * stream the same train rows share one L2 (dealt round-robin, the blocks of a frame would pull its rows through all
      * eight L2s) */
-    const int n_qblocks = (out_stride + 127) / 128;
+    const int n_qblocks = (out_stride + MX_QBLOCK - 1) / MX_QBLOCK;
     const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int qblock = logical % n_qblocks, chunk = (logical / n_qblocks) % n_chunks, frame = logical / (n_qblocks * n_chunks);
     int tframe = frame + train_frame_shift;
@@ -2508,9 +2520,9 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
     const uint8_t *tf = train_x + (size_t)tframe * t_frame_stride;
     const int lane = lane_id(), col = lane & 31, half = lane >> 5;
     const int wave = rfl((int)(threadIdx.x >> 6));
-    const int qbase = qblock * 128 + wave * 32; /* this wave's 32 queries: one B tile */
+    const int qbase = qblock * MX_QBLOCK + wave * (32 * MX_QT); /* this wave's 64 queries: two B tiles */
     const int c0 = chunk * chunk_len, c1 = imin(c0 + chunk_len, nt);
-    const int n_tiles = qblock * 128 < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
+    const int n_tiles = qblock * MX_QBLOCK < nq ? (imax(c1 - c0, 0) + MM_TILE - 1) / MM_TILE : 0;
 
     /* source offsets of this lane's pieces inside a tile (the same for every tile): DMA m of the tile covers units
      * 64 m .. 64 m + 63; wave w issues m = w (and m = 4 for wave 0) */
@@ -2521,128 +2533,275 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         const int r = u / (MX_PITCH / 16), j = imin(u - r * (MX_PITCH / 16), SS_X_ROW / 16 - 1);
         src_off[k] = (uint32_t)(r * SS_X_ROW + j * 16);
     }
+    const uint8_t *tsrc = tf + (size_t)c0 * SS_X_ROW; /* first row of the chunk */
+    const int last_tile = imax(n_tiles - 1, 0);
     /* every wave issues its DMAs for EVERY tile slot of the ring, also past the last tile (a harmless re-read of the
      * last tile): the count of vector-memory operations in flight is then the same in every phase, which is what the
-     * counted waits below rely on */
-    auto dma_tile = [&](int tile) {
-#if defined(MX_EXP) && MX_EXP == 1 /* timing experiment: no DMA after the prologue */
+     * counted waits below rely on.  `slot_off` = byte offset of the ring slot (wave-uniform). */
+    auto dma_tile = [&](int tile, int slot_off, auto ndma_c) {
+        constexpr int NDMA = decltype(ndma_c)::value;
+#if defined(MX_EXP) && MX_EXP == 1 /* timing experiment: no DMA after the prologue (stale tiles: wrong results) */
         if (tile >= MX_NBUF - 1) return;
 #endif
-#if defined(MX_EXP) && MX_EXP == 2 /* timing experiment: every DMA re-reads tile 0 (L2-hot) */
-        const int t = 0;
-#else
-        const int t = imin(tile, imax(n_tiles - 1, 0));
-#endif
-        const uint8_t *src = tf + (size_t)(c0 + t * MM_TILE) * SS_X_ROW;
-        uint8_t *dst = tiles[tile % MX_NBUF];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int m = wave + 4 * k;
-            if (m < MX_DMAS)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + src_off[k]),
-                                                 (__attribute__((address_space(3))) void *)(dst + m * 1024), 16, 0, 0);
-        }
+        const uint8_t *src = tsrc + (size_t)(uint32_t)(imin(tile, last_tile) * (MM_TILE * SS_X_ROW));
+        uint8_t *dst = &tiles[0][0] + slot_off + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + src_off[0]),
+                                         (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        if (NDMA == 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + src_off[1]),
+                                             (__attribute__((address_space(3))) void *)(dst + 4096), 16, 0, 0);
     };
-    /* B fragments: k-step s, lane half h <-> bytes 32 s + 16 h .. + 15 of the query row (bits 64 s + 32 h .. + 31), sign flipped */
-    v4i bq4[4];
-    {
-        const int qi = qbase + col;
+    /* B fragments of query tile u: k-step s, lane half h <-> bytes 32 s + 16 h .. + 15 of the query row (bits 64 s + 32 h .. + 31),
+     * sign flipped */
+    v4i bq4[MX_QT][4];
+#pragma unroll
+    for (int u = 0; u < MX_QT; u++) {
+        const int qi = qbase + 32 * u + col;
         const uint8_t *qrow = qf + (size_t)(qi < nq ? qi : 0) * SS_X_ROW + 16 * half;
 #pragma unroll
-        for (int sstep = 0; sstep < 4; sstep++) bq4[sstep] = *(const v4i *)(qrow + 32 * sstep);
+        for (int sstep = 0; sstep < 4; sstep++) bq4[u][sstep] = *(const v4i *)(qrow + 32 * sstep);
     }
-    if (n_tiles > 0) {
-#pragma unroll
-        for (int t = 0; t < MX_NBUF - 1; t++) dma_tile(t);
-    }
-    v8i bq[4];
-#pragma unroll
-    for (int sstep = 0; sstep < 4; sstep++) {
-        const v4i f = bq4[sstep] ^ (int)0x88888888;
-        bq[sstep] = v8i{f[0], f[1], f[2], f[3], 0, 0, 0, 0};
-    }
-    /* +32 everywhere: A0[m][0] = 4.0, B0[0][n] = 4.0 (FP4 0x6), block scale 2^1, every other element 0 (k-slot 0 lives in
-     * nibble 0 of lanes 0..31) */
-    const v8i ab_step = v8i{half == 0 ? 6 : 0, 0, 0, 0, 0, 0, 0, 0};
-    v16f crow; /* accumulator input of the next tile: 2^20 + row index in the chunk */
-#pragma unroll
-    for (int r = 0; r < 16; r++) crow[r] = (float)((1 << 20) + 4 * half + (r & 3) + 8 * (r >> 2));
-    const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
-    const int q_lo = qbase, q_hi = qbase + 32;
-    uint32_t k1[2], k2[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) k1[c] = k2[c] = 0xFFFFFFFFu;
-    /* Phase i: { wait: this wave's DMAs of tile i have landed (those of the MX_NBUF - 2 younger tiles may still fly) |
-     * barrier: so have everybody's, and everybody has finished reading tile i - 1 | refill tile i - 1's buffer with tile
-     * i + MX_NBUF - 1 | 4 + 1 MFMAs on tile i | selection }.  An LDS-DMA is a pending LDS write that only the issuing
-     * wave's vmcnt tracks; hipcc does not always count it when it places the waits of __syncthreads() (one loop barrier
-     * came out with lgkmcnt(0) only), hence the explicit counted waits and the raw barrier. */
-    for (int i = 0; i < n_tiles; i++) {
-#if defined(MX_EXP) && MX_EXP == 1
-        mx_wait_vm<0>();
+#if defined(MX_EXP) && MX_EXP == 3 /* timing experiment: the tile stream alone, no MFMA, no selection */
+    const bool active = false;
 #else
-        if (wave == 0) mx_wait_vm<2 * (MX_NBUF - 2)>();
-        else mx_wait_vm<1 * (MX_NBUF - 2)>();
+    const bool active = qbase < nq; /* wave-uniform: a wave without valid queries only helps with the tiles */
 #endif
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t k1[MX_QT], k2[MX_QT];
+#pragma unroll
+    for (int u = 0; u < MX_QT; u++) k1[u] = k2[u] = MX_INIT_KEY;
+
+    /* The loop, in one version per wave role (DMAs per tile: wave 0 issues two, the others one; a wave without valid
+     * queries only streams) so that nothing role-dependent is tested inside it.
+     * Step t: { wait: this wave's DMAs of tile t + 1 have landed (those of the MX_NBUF - 3 younger tiles may still fly) |
+     * barrier: so have everybody's | DMA of tile t + MX_NBUF - 1 into the slot tile t - 1 had (its last reader finished a
+     * step ago) | 4 x 2 MFMAs on tile t, whose fragments are in registers since the previous step | LDS reads of tile t + 1's
+     * fragments | between the MFMAs: the selection of tile t - 1 }.  Fragments and accumulators are double buffered, so no
+     * LDS latency and no selection stands between a barrier and the MFMAs behind it: with the reads and the selection inside
+     * the step of their own tile the waves of a CU fell into step and the matrix pipe idled through both.
+     * An LDS-DMA is a pending LDS write that only the issuing wave's vmcnt tracks; hipcc does not always count it when it
+     * places the waits of __syncthreads() (one loop barrier came out with lgkmcnt(0) only), hence the explicit counted waits
+     * and the raw barrier. */
+    auto run = [&](auto ndma_c, auto active_c) {
+        constexpr int NDMA = decltype(ndma_c)::value;
+        constexpr bool ACTIVE = decltype(active_c)::value;
+#pragma unroll
+        for (int t = 0; t < MX_NBUF - 1; t++) dma_tile(t, t * MX_BUF, ndma_c);
+        int wr_off = (MX_NBUF - 1) * MX_BUF;
+        auto sync_step = [&](int t) {
+            mx_wait_vm<NDMA * (MX_NBUF - 3)>();
+#if !(defined(MX_EXP) && MX_EXP == 5) /* timing experiment 5: no barrier (races: wrong results) */
+            __builtin_amdgcn_s_barrier();
+#endif
+            asm volatile("" ::: "memory");
+            dma_tile(t + MX_NBUF - 1, wr_off, ndma_c);
+            wr_off = wr_off == (MX_NBUF - 1) * MX_BUF ? 0 : wr_off + MX_BUF;
+        };
+        /* tile 0 has landed everywhere before anybody reads it */
+        mx_wait_vm<NDMA * (MX_NBUF - 2)>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        dma_tile(i + MX_NBUF - 1);
-        if (!active) continue;
-        const int j0 = c0 + i * MM_TILE;
-        const uint8_t *arow = &tiles[i % MX_NBUF][col * MX_PITCH + 16 * half];
-        const bool masked = j0 + MM_TILE > c1 || (excl && j0 < q_hi && j0 + MM_TILE > q_lo);
-        v16f acc;
-        v4i a4 = *(const v4i *)arow;
-        v8i a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
-        if (masked) {
-            const int rows_valid = c1 - j0, skip = excl ? qbase + col - j0 : -1;
-            v16f ci;
+        if (!ACTIVE) {
+            for (int t = 0; t < n_tiles; t++) sync_step(t);
+            return;
+        }
+        v8i bq[MX_QT][4];
+        v16f crow; /* accumulator input of every tile: 2^20 + 8160 + row in the tile */
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = 4 * half + (r & 3) + 8 * (r >> 2);
-                ci[r] = crow[r] + ((row >= rows_valid || row == skip) ? MX_NONE_F : 0.0f);
+        for (int u = 0; u < MX_QT; u++)
+#pragma unroll
+            for (int sstep = 0; sstep < 4; sstep++) {
+                const v4i f = bq4[u][sstep] ^ (int)0x88888888;
+                bq[u][sstep] = v8i{f[0], f[1], f[2], f[3], 0, 0, 0, 0};
             }
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0], ci, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
-        } else {
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[0], crow, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
-        }
 #pragma unroll
-        for (int sstep = 1; sstep < 4; sstep++) {
-            a4 = *(const v4i *)(arow + 32 * sstep);
-            a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[sstep], acc, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
+        for (int r = 0; r < 16; r++) crow[r] = (float)((1 << 20) + MX_FIELD0 + 4 * half + (r & 3) + 8 * (r >> 2));
+        /* tiles whose keys need masking: the last one when the chunk does not end on a tile, and the (up to two) tiles that
+         * hold this wave's own 64 rows in a self-match.  The tile range is cut into plain and masked SEGMENTS so that the
+         * plain loop tests nothing: A = [0, e1) plain, B = [e1, e2) masked, C = [e2, e3) plain, D = [e3, n) masked. */
+        const int p_part = ((c1 - c0) & (MM_TILE - 1)) ? n_tiles - 1 : n_tiles;
+        const bool self_here = excl && qbase + 32 * MX_QT > c0 && qbase < c1;
+        const int m0 = self_here ? imin(imax(qbase - c0, 0) / MM_TILE, n_tiles) : n_tiles;
+        const int m1 = self_here ? imin((qbase + 32 * MX_QT - c0) / MM_TILE, n_tiles) : n_tiles;
+        const int e1 = imin(m0, p_part), e2 = m0 <= p_part ? m1 : n_tiles, e3 = imax(e2, p_part);
+        const uint32_t a_base = (uint32_t)(col * MX_PITCH + 16 * half);
+        int rd_off = 0;
+        v4i afr[2][4];   /* A fragments of the tile of this step (parity P) and of the next one */
+        v16f acc[2][MX_QT];
+        auto read_frags = [&](v4i(&a4)[4]) {
+            const uint8_t *arow = &tiles[0][0] + (a_base + (uint32_t)rd_off);
+            rd_off = rd_off == (MX_NBUF - 1) * MX_BUF ? 0 : rd_off + MX_BUF;
+#if defined(MX_EXP) && MX_EXP == 6 /* timing experiment 6: no LDS reads (wrong results) */
+#pragma unroll
+            for (int sstep = 0; sstep < 4; sstep++) a4[sstep] = bq4[0][sstep] + (int)(uintptr_t)arow;
+#else
+#pragma unroll
+            for (int sstep = 0; sstep < 4; sstep++) a4[sstep] = *(const v4i *)(arow + 32 * sstep);
+#endif
+        };
+        auto mfma_tile = [&](int t, const v4i(&a4)[4], v16f(&ac)[MX_QT], auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+            for (int sstep = 0; sstep < 4; sstep++) {
+                const v8i a = v8i{a4[sstep][0], a4[sstep][1], a4[sstep][2], a4[sstep][3], 0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < MX_QT; u++) {
+                    v16f ci = sstep == 0 ? crow : ac[u];
+                    if (MASKED && sstep == 0) { /* rows that must not compete enter with 2^28 */
+                        const int j0 = c0 + t * MM_TILE, rows_valid = c1 - j0, skip = excl ? qbase + 32 * u + col - j0 : -1;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int row = 4 * half + (r & 3) + 8 * (r >> 2);
+                            ci[r] += (row >= rows_valid || row == skip) ? MX_NONE_F : 0.0f;
+                        }
+                    }
+                    ac[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[u][sstep], ci, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
+                }
+            }
+        };
+        auto select_tile = [&](v16f(&ac)[MX_QT]) {
+#if defined(MX_EXP) && MX_EXP == 4 /* timing experiment 4: no selection (one key per tile keeps the MFMAs alive) */
+            k1[0] = min(k1[0], __float_as_uint(ac[0][0]));
+            k1[1] = min(k1[1], __float_as_uint(ac[1][0]));
+            return;
+#endif
+            /* the running keys fall behind every key of this tile */
+#pragma unroll
+            for (int u = 0; u < MX_QT; u++) {
+                k1[u] = __float_as_uint(__uint_as_float(k1[u]) - 32.0f);
+                k2[u] = __float_as_uint(__uint_as_float(k2[u]) - 32.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < MX_QT; u++) mx_select(ac[u], k1[u], k2[u]);
+        };
+        /* step t: P = t & 1 names the buffers of tile t */
+        auto step = [&](int t, auto p_c, auto masked_c, auto first_c) {
+            constexpr int P = decltype(p_c)::value;
+            sync_step(t);
+            mfma_tile(t, afr[P], acc[P], masked_c);
+            read_frags(afr[1 - P]); /* tile t + 1 (past the end: a landed slot, never used) */
+            if (!decltype(first_c)::value) select_tile(acc[1 - P]);
+        };
+        auto segment = [&](int b, int e, auto masked_c) {
+            int t = b;
+            if (t < e && (t & 1)) {
+                step(t, std::integral_constant<int, 1>{}, masked_c, std::false_type{});
+                t++;
+            }
+            for (; t + 1 < e; t += 2) {
+                step(t, std::integral_constant<int, 0>{}, masked_c, std::false_type{});
+                step(t + 1, std::integral_constant<int, 1>{}, masked_c, std::false_type{});
+            }
+            if (t < e) step(t, std::integral_constant<int, 0>{}, masked_c, std::false_type{});
+        };
+        read_frags(afr[0]);
+        /* tile 0 has no predecessor to select */
+        if (e1 > 0) step(0, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+        else step(0, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+        segment(1, e1, std::false_type{});
+        segment(imax(e1, 1), e2, std::true_type{});
+        segment(imax(e2, 1), e3, std::false_type{});
+        segment(imax(e3, 1), n_tiles, std::true_type{});
+        if (n_tiles & 1) select_tile(acc[0]);
+        else select_tile(acc[1]);
+    };
+    if (n_tiles > 0) {
+        if (active) {
+            if (wave == 0) run(std::integral_constant<int, 2>{}, std::true_type{});
+            else run(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            if (wave == 0) run(std::integral_constant<int, 2>{}, std::false_type{});
+            else run(std::integral_constant<int, 1>{}, std::false_type{});
         }
-        crow = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ab_step, ab_step, crow, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 1, 0, MX_SCALE_ONE);
-        mx_select(acc, k1, k2);
     }
     mx_wait_vm<0>(); /* nothing of this block may still be writing LDS when the block retires */
-    /* fold the two chains of a lane, then lanes l and l + 32 (same query, different train rows) */
-    uint32_t f1 = min(k1[0], k1[1]), f2 = min(max(k1[0], k1[1]), min(k2[0], k2[1]));
-    const uint32_t o1 = (uint32_t)__shfl_xor((int)f1, 32, 64), o2 = (uint32_t)__shfl_xor((int)f2, 32, 64);
-    const uint32_t b1 = min(f1, o1), b2 = min(max(f1, o1), min(f2, o2));
-    const int qi = qbase + col;
-    if (half != 0 || qi >= out_stride) return;
-    const bool qvalid = qi < nq;
-    /* keys are bit patterns of non-negative floats 8192 * hamming + row (< 2^22), or >= 2^28 / all ones for "none" */
-    const bool none1 = b1 >= __float_as_uint(MX_NONE_F), none2 = b2 >= __float_as_uint(MX_NONE_F);
-    const uint32_t m1 = none1 ? 0u : (uint32_t)__uint_as_float(b1), m2 = none2 ? 0u : (uint32_t)__uint_as_float(b2);
-    const int d1 = none1 ? 0xFFFF : (int)(m1 >> MX_ROW_BITS); /* only excluded rows were seen: none */
-    const int d2 = none2 ? 0xFFFF : (int)(m2 >> MX_ROW_BITS);
-    const int j1 = none1 ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1));
-    if (n_chunks > 1) {
+    /* lanes l and l + 32 hold the same queries over the two groups of every tile */
+#pragma unroll
+    for (int u = 0; u < MX_QT; u++) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)k1[u], 32, 64), o2 = (uint32_t)__shfl_xor((int)k2[u], 32, 64);
+        const uint32_t b1 = min(k1[u], o1), b2 = min(max(k1[u], o1), min(k2[u], o2));
+        const int qi = qbase + 32 * u + col;
+        if (half != 0 || qi >= out_stride) continue;
+        /* keys are bit patterns of non-negative floats 8192 * hamming + field (< 2^22), or >= 2^28 for "none"; a key born in
+         * tile t has lost 32 for each of the n_tiles - 1 - t later tiles */
+        const bool none1 = b1 >= __float_as_uint(MX_NONE_F), none2 = b2 >= __float_as_uint(MX_NONE_F);
+        const uint32_t m1 = none1 ? 0u : (uint32_t)__uint_as_float(b1), m2 = none2 ? 0u : (uint32_t)__uint_as_float(b2);
         match_partial mp;
-        mp.d1 = (uint16_t)d1;
-        mp.d2 = (uint16_t)d2;
-        mp.j1 = j1;
+        mp.d1 = (uint16_t)(none1 ? 0xFFFF : (int)(m1 >> MX_ROW_BITS)); /* only excluded rows were seen: none */
+        mp.d2 = (uint16_t)(none2 ? 0xFFFF : (int)(m2 >> MX_ROW_BITS));
+        mp.j1 = none1 ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1)) - MX_FIELD0 + MM_TILE * (n_tiles - 1);
         partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
-    } else {
-        const size_t o = (size_t)frame * out_stride + qi;
-        const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
-        idx_out[o] = ok ? j1 : -1;
-        d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
-        d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
     }
+}
+
+/* The second half of k_match_mfma_x: folds the chunk partials of a query (n_chunks >= 1; 0 = they have been folded
+ * into the output arrays already, by k_match_merge_wide in raw mode), then recomputes the distances of the query to the
+ * three other rows of the best row's GROUP (the aligned block of four rows) -- the only rows the partials' second best does
+ * not cover -- and applies the acceptance test.  The block is 4 ROWB contiguous bytes; the lanes of a query read it in
+ * consecutive 16-byte pieces (whole lines), lane g piece g % (ROWB / 16) of row g / (ROWB / 16).
+ * PACKED rows (32 bytes, where the caller has them): 8 lanes per query.  EXPANDED rows (128 bytes of FP4 +1 (0x2) / -1 (0xA)
+ * nibbles: two rows differ in a bit where the nibbles' sign bits differ): 32 lanes per query. */
+template <int ROWB>
+__global__ __launch_bounds__(256) void k_match_finish_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
+                                                        const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr, int nq_fixed,
+                                                        int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift,
+                                                        int exclude_self_mode, const match_partial *__restrict__ partial, int n_chunks, int th,
+                                                        int rnum, int rden, int out_stride, int32_t *__restrict__ idx_out,
+                                                        uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
+{
+    constexpr int LPQ = ROWB / 4;        /* lanes per query: 8 or 32 */
+    constexpr int LPR = ROWB / 16;       /* lanes per row: 2 or 8 */
+    const int frame = blockIdx.y, g = threadIdx.x & (LPQ - 1);
+    const int qi = blockIdx.x * (256 / LPQ) + (threadIdx.x / LPQ);
+    if (qi >= out_stride) return; /* the LPQ lanes of a query leave together */
+    int tframe = frame + train_frame_shift;
+    if (tframe < 0) tframe = 0;
+    const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
+    const int nt = nt_arr ? nt_arr[tframe] : nt_fixed;
+    const bool excl = exclude_self_mode == 1 || (exclude_self_mode == 2 && tframe == frame);
+    const size_t o = (size_t)frame * out_stride + qi;
+    int d1 = 0xFFFF, d2 = 0xFFFF, j1 = -1;
+    if (n_chunks == 0) {
+        d1 = d1_out[o];
+        d2 = d2_out[o];
+        j1 = idx_out[o];
+    } else {
+        for (int c = 0; c < n_chunks; c++) {
+            const match_partial mp = partial[((size_t)frame * n_chunks + c) * out_stride + qi];
+            merge_partial(d1, j1, d2, mp.d1, mp.j1, mp.d2);
+        }
+    }
+    const bool qvalid = qi < nq;
+    int cand = 0xFFFF;
+    if (qvalid && j1 >= 0) {
+        const int row = (j1 & ~3) + g / LPR;
+        const uint32_t mask = ROWB == SS_X_ROW ? 0x88888888u : 0xFFFFFFFFu;
+        const uint4 a = *(const uint4 *)(query_x + (size_t)frame * q_frame_stride + (size_t)qi * ROWB + 16 * (g & (LPR - 1)));
+        /* rows past the train set are not allocated everywhere */
+        const uint4 b = row < nt ? *(const uint4 *)(train_x + (size_t)tframe * t_frame_stride + (size_t)row * ROWB + 16 * (g & (LPR - 1))) : a;
+        int h = __builtin_popcount((a.x ^ b.x) & mask) + __builtin_popcount((a.y ^ b.y) & mask) + __builtin_popcount((a.z ^ b.z) & mask) +
+                __builtin_popcount((a.w ^ b.w) & mask);
+        /* sum over the LPR lanes of the row */
+        h += __builtin_amdgcn_update_dpp(0, h, 0xB1, 0xF, 0xF, false); /* quad_perm [1,0,3,2] */
+        if (LPR == 8) {
+            h += __builtin_amdgcn_update_dpp(0, h, 0x4E, 0xF, 0xF, false);  /* quad_perm [2,3,0,1] */
+            h += __builtin_amdgcn_update_dpp(0, h, 0x141, 0xF, 0xF, false); /* row_half_mirror: the other quad of the 8 */
+        }
+        if (row < nt && row != j1 && !(excl && row == qi)) cand = h;
+    }
+    /* minimum over the four rows = over the four row slots of the query's lanes */
+    if (LPR == 2) {
+        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1]: the other row of the quad */
+        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x141, 0xF, 0xF, false)); /* row_half_mirror: the other quad */
+    } else {
+        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x140, 0xF, 0xF, false)); /* row_mirror: the other 8 of the 16 */
+        cand = imin(cand, (int)__shfl_xor(cand, 16, 64));                                   /* the other 16 of the 32 */
+    }
+    d2 = imin(d2, cand);
+    if (g != 0) return;
+    const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
+    idx_out[o] = ok ? j1 : -1;
+    d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+    d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
 }
 
 __global__ __launch_bounds__(256) void k_match_merge(const match_partial *__restrict__ partial, const int32_t *__restrict__ nq_arr,
@@ -2997,21 +3156,44 @@ int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_
     return (int)(((long)n_train_max + len - 1) / len > 0 ? ((long)n_train_max + len - 1) / len : 1);
 }
 
-/* batch form on expanded descriptors (desc_x of the extraction): same arguments as ssk_match, strides in BYTES */
+/* batch form on expanded descriptors (desc_x of the extraction): same arguments as ssk_match, strides in BYTES.  Two
+ * launches: k_match_mfma_x writes one partial per (query, chunk), k_match_finish_x folds them, adds the second best inside
+ * the best row's group and applies the acceptance test. */
 void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
                  int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
                  int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
-                 uint16_t *d1, uint16_t *d2, int n_frames)
+                 uint16_t *d1, uint16_t *d2, int n_frames, const uint8_t *query_p, const uint8_t *train_p, int64_t qp_frame_stride,
+                 int64_t tp_frame_stride)
 {
-    dim3 grid(((out_stride + 127) / 128) * n_chunks * n_frames);
+    dim3 grid(((out_stride + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks * n_frames);
     hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
-                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, th, rnum, rden, out_stride,
-                       (match_partial *)partial, idx, d1, d2);
-    if (n_chunks > 1) {
-        dim3 g2((out_stride + 255) / 256, n_frames);
-        hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, (const match_partial *)partial, nq_arr, nq_fixed, n_chunks, th, rnum,
-                           rden, out_stride, idx, d1, d2);
-    }
+                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial);
+    if (query_p && train_p) /* the same rows as packed descriptors: the finish reads those */
+        hipLaunchKernelGGL(k_match_finish_x<32>, dim3((out_stride + 31) / 32, n_frames), dim3(256), 0, s, query_p, train_p, nq_arr, nt_arr, nq_fixed, nt_fixed, qp_frame_stride,
+                           tp_frame_stride, train_frame_shift, exclude_self_mode, (const match_partial *)partial, n_chunks, th, rnum, rden, out_stride,
+                           idx, d1, d2);
+    else
+        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, dim3((out_stride + 7) / 8, n_frames), dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+                           t_frame_stride, train_frame_shift, exclude_self_mode, (const match_partial *)partial, n_chunks, th, rnum, rden, out_stride,
+                           idx, d1, d2);
+}
+
+/* chunk plan of a batch: rows_q query rows and rows_t train rows per frame.  About 2000 blocks of 256 queries x one chunk of
+ * >= 8 tiles */
+int ssk_match_x_batch_chunks(int rows_q, int rows_t, int n_frames, int *chunk_len)
+{
+    const int q_groups = ((rows_q + MX_QBLOCK - 1) / MX_QBLOCK) * (n_frames > 0 ? n_frames : 1);
+    int want = (2048 + q_groups / 2) / q_groups;
+    if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) want = atoi(e); /* experiments */
+    const int max_chunks = (rows_t + 255) / 256;
+    if (want > max_chunks) want = max_chunks;
+    if (want < 1) want = 1;
+    int len = ((rows_t + want - 1) / want + MM_TILE - 1) & ~(MM_TILE - 1);
+    if (len > (1 << MX_ROW_BITS)) len = 1 << MX_ROW_BITS;
+    if (len < MM_TILE) len = MM_TILE;
+    *chunk_len = len;
+    const int n = (rows_t + len - 1) / len;
+    return n < 1 ? 1 : n;
 }
 
 void ssk_expand_desc(hipStream_t s, const void *packed, int n, void *out)
@@ -3031,36 +3213,30 @@ void ssk_expand_desc_frames(hipStream_t s, const void *packed, int rows, int n_f
                            (int64_t)rows * 8, (int64_t)n_alloc * SS_X_ROW);
 }
 
-/* one query set against one (large) train set, both expanded: chunks of <= 8192 rows (the key's row field), the 16
- * query blocks of a chunk adjacent in the grid (one XCD streams the chunk once) */
-int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len)
-{
-    const int n_qblocks = (n_query + 127) / 128;
-    int want = (2048 + n_qblocks - 1) / n_qblocks; /* >= 2048 blocks when the train set allows */
-    const int max_chunks = (n_train + 255) / 256;  /* >= 8 tiles per block */
-    if (want > max_chunks) want = max_chunks;
-    if (want < 1) want = 1;
-    int len = ((n_train + want - 1) / want + MM_TILE - 1) & ~(MM_TILE - 1);
-    if (len > (1 << MX_ROW_BITS)) len = 1 << MX_ROW_BITS;
-    if (len < MM_TILE) len = MM_TILE;
-    *chunk_len = len;
-    const int n = (n_train + len - 1) / len;
-    return n < 1 ? 1 : n;
-}
+/* one query set against one (large) train set, both expanded: chunks of <= 8192 rows (the key's row field), the query
+ * blocks of a chunk adjacent in the grid (one XCD streams the chunk once) */
+int ssk_match_x_chunks(int n_query, int n_train, int *chunk_len) { return ssk_match_x_batch_chunks(n_query, n_train, 1, chunk_len); }
 
 void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uint8_t *train_x, int nt, int chunk_len, int n_chunks,
-                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2)
+                        int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2,
+                        const uint8_t *query_p, const uint8_t *train_p)
 {
-    dim3 grid(((nq + 127) / 128) * n_chunks);
+    dim3 grid(((nq + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks);
     hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
-                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, th, rnum, rden, nq, (match_partial *)partial,
-                       idx, d1, d2);
-    if (n_chunks >= 32)
-        hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, th, rnum, rden, nq,
-                           idx, d1, d2);
-    else if (n_chunks > 1)
-        hipLaunchKernelGGL(k_match_merge, dim3((nq + 255) / 256, 1), dim3(256), 0, s, (const match_partial *)partial,
-                           (const int32_t *)nullptr, nq, n_chunks, th, rnum, rden, nq, idx, d1, d2);
+                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial);
+    int fin_chunks = n_chunks;
+    if (n_chunks >= 32) { /* many chunks: one wave per query folds them (raw: no acceptance test yet), the finish reads the outputs */
+        hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, -1, 1, 1, nq, idx, d1, d2);
+        fin_chunks = 0;
+    }
+    if (query_p && train_p)
+        hipLaunchKernelGGL(k_match_finish_x<32>, dim3((nq + 31) / 32, 1), dim3(256), 0, s, query_p, train_p, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, nq, nt, (int64_t)0, (int64_t)0, 0, exclude_self ? 1 : 0, (const match_partial *)partial,
+                           fin_chunks, th, rnum, rden, nq, idx, d1, d2);
+    else
+        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, dim3((nq + 7) / 8, 1), dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr, nq, nt, (int64_t)0, (int64_t)0, 0, exclude_self ? 1 : 0, (const match_partial *)partial,
+                           fin_chunks, th, rnum, rden, nq, idx, d1, d2);
 }
 
 void ssk_match(hipStream_t s, const void *query, const void *train, const int32_t *nq_arr, const int32_t *nt_arr,
