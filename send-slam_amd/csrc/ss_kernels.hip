@@ -2447,14 +2447,15 @@ __global__ __launch_bounds__(64 * MM_WAVES, NU == 2 ? 2 : 4) void k_match_mfma(c
 /*   row field of the NEW keys per tile (round 2: a fifth MFMA), the two RUNNING keys of a lane lose 32 per tile (two            */
 /*   v_sub_f32): older rows then always carry the smaller field, which is all the ordering needs; the field is decoded at        */
 /*   the end.  Chunks are <= 8192 rows (13-bit field).                                                                            */
-/* * selection by GROUPS.  A lane's 16 accumulator registers are, for one query, four aligned blocks of four consecutive        */
-/*   train rows.  The lane reduces each block to its minimum (v_min3_u32 + v_min_u32) and keeps the two smallest block minima     */
-/*   (v_med3_u32 + v_min_u32 per block): 16 vector instructions per tile and query tile where the pairwise best / second-best      */
-/*   took 32 -- round 2's kernel was bound by vector ISSUE (every MFMA also holds the issue port for 8 cycles), not by the         */
-/*   matrix pipe.  What is kept is exact for the best (distance, row) and for the second best OVER THE OTHER BLOCKS; the second    */
-/*   best inside the best row's own block -- three rows, one 128-byte line of packed descriptors -- is recomputed by               */
-/*   k_match_finish_x after the chunk partials have been folded (second = min(second over the other blocks, best of those          */
-/*   three)).  Nothing is approximated.                                                                                            */
+/* * selection by GROUPS.  A lane's 16 accumulator registers are, for one query, four runs of four consecutive train rows        */
+/*   (aligned blocks of four).  The lane reduces each GROUP of MX_RUNS runs to its minimum (v_min3_u32 / v_min_u32) and keeps the  */
+/*   two smallest group minima (v_med3_u32 + v_min_u32 per group): 16 vector instructions per tile and query tile with one-run     */
+/*   groups, 10 with one group of all four runs, where the pairwise best / second-best took 32 -- round 2's kernel was bound by    */
+/*   vector ISSUE (every MFMA also holds the issue port for 8 cycles), not by the matrix pipe.  What is kept is exact for the      */
+/*   best (distance, row) and for the second best OVER THE OTHER GROUPS; the second best inside the best row's own group --         */
+/*   3 rows in one 128-byte line of packed descriptors (15 rows in four lines with four-run groups) -- is recomputed once the       */
+/*   best is final: in this kernel's epilogue when one chunk covers the train set (FUSED), else by k_match_finish_x after the       */
+/*   chunk partials have been folded (second = min(second over the other groups, best of those rows)).  Nothing is approximated.    */
 /* * rows that must not compete (past the chunk, or the query itself) get 2^28 added to their keys, in the few tiles that         */
 /*   contain such rows (wave-uniform test).                                                                                       */
 /* ------------------------------------------------------------------------------------ */
@@ -2479,18 +2480,28 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define MX_WAVES_PER_SIMD 2
 #endif
 
-/* a lane's 16 keys are four GROUPS of four consecutive train rows (registers 4 g .. 4 g + 3 = rows 8 g + 4 half .. + 3 of the
- * tile: the aligned block of four rows): the minimum of each group, then the two smallest group minima seen so far */
+/* A lane's 16 keys are, for one query, four RUNS of four consecutive train rows (registers 4 k .. 4 k + 3 = rows
+ * 8 k + 4 half .. + 3 of the tile).  MX_RUNS consecutive runs form a GROUP: the minimum of each group, then the two smallest
+ * group minima seen so far.  Larger groups = fewer vector instructions here (4 runs: 10, 2 runs: 12, 1 run: 16 per tile) and
+ * more rows to re-examine once the best is final (15 / 7 / 3 rows in 4 / 2 / 1 lines of packed descriptors). */
+#ifndef MX_RUNS
+#define MX_RUNS 1 /* measured, 64 x 2000^2 in one fused launch: 1 run 41.8 us, 2 runs 43.2, 4 runs 46.7 (the epilogue's lines decide) */
+#endif
 __device__ __forceinline__ void mx_select(const v16f &acc, uint32_t &k1, uint32_t &k2)
 {
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const uint32_t m = min(min(min(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1])), __float_as_uint(acc[4 * g + 2])),
-                               __float_as_uint(acc[4 * g + 3])); /* v_min3_u32 + v_min_u32 */
-        k2 = min(max(k1, k2), max(min(k1, k2), m));              /* v_med3_u32 */
+    for (int gr = 0; gr < 4 / MX_RUNS; gr++) {
+        const int r0 = 4 * MX_RUNS * gr;
+        uint32_t m = min(min(__float_as_uint(acc[r0]), __float_as_uint(acc[r0 + 1])), __float_as_uint(acc[r0 + 2])); /* v_min3_u32 */
+#pragma unroll
+        for (int r = r0 + 3; r + 1 < r0 + 4 * MX_RUNS; r += 2) m = min(min(m, __float_as_uint(acc[r])), __float_as_uint(acc[r + 1]));
+        m = min(m, __float_as_uint(acc[r0 + 4 * MX_RUNS - 1]));
+        k2 = min(max(k1, k2), max(min(k1, k2), m)); /* v_med3_u32 */
         k1 = min(k1, m);
     }
 }
+/* first row of the first run of row j's group */
+__device__ __forceinline__ int mx_group_base(int j) { return (j & ~31) + 8 * MX_RUNS * ((j & 31) / (8 * MX_RUNS)) + 4 * ((j >> 2) & 1); }
 
 template <int N> __device__ __forceinline__ void mx_wait_vm()
 {
@@ -2498,11 +2509,21 @@ template <int N> __device__ __forceinline__ void mx_wait_vm()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+/* what the FUSED epilogue needs: the packed descriptors of both sides and the outputs */
+struct mx_finish {
+    const uint8_t *query_p, *train_p; /* packed rows, 32 bytes each */
+    int64_t qp_frame_stride, tp_frame_stride;
+    int th, rnum, rden;
+    int32_t *idx_out;
+    uint16_t *d1_out, *d2_out;
+};
+
+template <bool FUSED> /* one chunk covers the train set: the kernel finishes its queries itself (no partials, no second launch) */
 __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
                                                        const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                        int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                        int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
-                                                       int out_stride, match_partial *__restrict__ partial)
+                                                       int out_stride, match_partial *__restrict__ partial, mx_finish fin)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[MX_NBUF][MX_BUF];
     /* 1-D grid, XCD-aware: every XCD gets a contiguous run of (frame, chunk, query block) triples, so the blocks that
@@ -2714,32 +2735,97 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         }
     }
     mx_wait_vm<0>(); /* nothing of this block may still be writing LDS when the block retires */
-    /* lanes l and l + 32 hold the same queries over the two groups of every tile */
+    /* lanes l and l + 32 hold the same queries over the two groups of every tile; keys are bit patterns of non-negative
+     * floats 8192 * hamming + field (< 2^22), or >= 2^28 for "none"; a key born in tile t has lost 32 for each of the
+     * n_tiles - 1 - t later tiles */
+    int r_d1[MX_QT], r_d2[MX_QT], r_j1[MX_QT];
 #pragma unroll
     for (int u = 0; u < MX_QT; u++) {
         const uint32_t o1 = (uint32_t)__shfl_xor((int)k1[u], 32, 64), o2 = (uint32_t)__shfl_xor((int)k2[u], 32, 64);
         const uint32_t b1 = min(k1[u], o1), b2 = min(max(k1[u], o1), min(k2[u], o2));
-        const int qi = qbase + 32 * u + col;
-        if (half != 0 || qi >= out_stride) continue;
-        /* keys are bit patterns of non-negative floats 8192 * hamming + field (< 2^22), or >= 2^28 for "none"; a key born in
-         * tile t has lost 32 for each of the n_tiles - 1 - t later tiles */
         const bool none1 = b1 >= __float_as_uint(MX_NONE_F), none2 = b2 >= __float_as_uint(MX_NONE_F);
         const uint32_t m1 = none1 ? 0u : (uint32_t)__uint_as_float(b1), m2 = none2 ? 0u : (uint32_t)__uint_as_float(b2);
-        match_partial mp;
-        mp.d1 = (uint16_t)(none1 ? 0xFFFF : (int)(m1 >> MX_ROW_BITS)); /* only excluded rows were seen: none */
-        mp.d2 = (uint16_t)(none2 ? 0xFFFF : (int)(m2 >> MX_ROW_BITS));
-        mp.j1 = none1 ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1)) - MX_FIELD0 + MM_TILE * (n_tiles - 1);
-        partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
+        r_d1[u] = none1 ? 0xFFFF : (int)(m1 >> MX_ROW_BITS); /* only excluded rows were seen: none */
+        r_d2[u] = none2 ? 0xFFFF : (int)(m2 >> MX_ROW_BITS);
+        r_j1[u] = none1 ? -1 : c0 + (int)(m1 & ((1u << MX_ROW_BITS) - 1)) - MX_FIELD0 + MM_TILE * (n_tiles - 1);
+    }
+    if (!FUSED) {
+#pragma unroll
+        for (int u = 0; u < MX_QT; u++) {
+            const int qi = qbase + 32 * u + col;
+            if (half != 0 || qi >= out_stride) continue;
+            match_partial mp;
+            mp.d1 = (uint16_t)r_d1[u];
+            mp.d2 = (uint16_t)r_d2[u];
+            mp.j1 = r_j1[u];
+            partial[((size_t)frame * n_chunks + chunk) * out_stride + qi] = mp;
+        }
+        return;
+    }
+    /* FUSED: the best is final.  Eight passes of eight queries; in a pass the eight lanes 8 s .. 8 s + 7 serve one query of
+     * the wave (query tile u = pass >> 2, column 8 (pass & 3) + s): lane g reads piece g (16 bytes: row g >> 1, half g & 1) of
+     * each of the four 128-byte runs of the best row's group (the eight read whole lines), popcounts it against its half of the
+     * query row, and the minimum over the group's other rows completes the second best.  Lane 8 s writes the query's outputs. */
+    const int g = lane & 7, slot = lane >> 3;
+    const uint8_t *qp = fin.query_p + (size_t)frame * fin.qp_frame_stride;
+    const uint8_t *tp = fin.train_p + (size_t)tframe * fin.tp_frame_stride;
+    /* two rounds of four passes: the 20 loads of a round are issued together (one memory round trip per round, not per pass) */
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+        int pj1[4], pd1[4], pd2[4];
+        uint4 pa[4], pb[4][MX_RUNS];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int src = 8 * k + slot; /* u = round is uniform in a pass */
+            pj1[k] = __shfl(r_j1[round], src, 64);
+            pd1[k] = __shfl(r_d1[round], src, 64);
+            pd2[k] = __shfl(r_d2[round], src, 64);
+            const int qi = qbase + 32 * round + src;
+            const bool live = qi < nq && pj1[k] >= 0;
+            const int base = live ? mx_group_base(pj1[k]) : 0;
+            pa[k] = *(const uint4 *)(qp + (size_t)(live ? qi : 0) * SS_DESC_BYTES + 16 * (g & 1));
+#pragma unroll
+            for (int run = 0; run < MX_RUNS; run++) {
+                const int row = base + 8 * run + (g >> 1);
+                /* rows past the train set are not allocated everywhere: read the query piece's address again instead */
+                pb[k][run] = live && row < nt ? *(const uint4 *)(tp + (size_t)row * SS_DESC_BYTES + 16 * (g & 1)) : pa[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int src = 8 * k + slot, qi = qbase + 32 * round + src;
+            const bool qvalid = qi < nq, live = qvalid && pj1[k] >= 0;
+            const int base = mx_group_base(pj1[k]);
+            int cand = 0xFFFF;
+#pragma unroll
+            for (int run = 0; run < MX_RUNS; run++) {
+                const int row = base + 8 * run + (g >> 1);
+                const uint4 a = pa[k], b = pb[k][run];
+                int h = __builtin_popcount(a.x ^ b.x) + __builtin_popcount(a.y ^ b.y) + __builtin_popcount(a.z ^ b.z) + __builtin_popcount(a.w ^ b.w);
+                h += __builtin_amdgcn_update_dpp(0, h, 0xB1, 0xF, 0xF, false); /* quad_perm [1,0,3,2]: the other half of the row */
+                if (live && row < nt && row != pj1[k] && !(excl && row == qi)) cand = imin(cand, h);
+            }
+            cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1]: the other row of the quad */
+            cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x141, 0xF, 0xF, false)); /* row_half_mirror: the other quad */
+            const int d1 = pd1[k], d2 = imin(pd2[k], cand);
+            if (g == 0 && qi < out_stride) {
+                const size_t o = (size_t)frame * out_stride + qi;
+                const bool ok = live && (fin.th < 0 || (d1 <= fin.th && d1 * fin.rden < d2 * fin.rnum));
+                fin.idx_out[o] = ok ? pj1[k] : -1;
+                fin.d1_out[o] = qvalid ? (uint16_t)d1 : (uint16_t)0xFFFF;
+                fin.d2_out[o] = qvalid ? (uint16_t)d2 : (uint16_t)0xFFFF;
+            }
+        }
     }
 }
 
-/* The second half of k_match_mfma_x: folds the chunk partials of a query (n_chunks >= 1; 0 = they have been folded
- * into the output arrays already, by k_match_merge_wide in raw mode), then recomputes the distances of the query to the
- * three other rows of the best row's GROUP (the aligned block of four rows) -- the only rows the partials' second best does
- * not cover -- and applies the acceptance test.  The block is 4 ROWB contiguous bytes; the lanes of a query read it in
- * consecutive 16-byte pieces (whole lines), lane g piece g % (ROWB / 16) of row g / (ROWB / 16).
- * PACKED rows (32 bytes, where the caller has them): 8 lanes per query.  EXPANDED rows (128 bytes of FP4 +1 (0x2) / -1 (0xA)
- * nibbles: two rows differ in a bit where the nibbles' sign bits differ): 32 lanes per query. */
+/* The second half of k_match_mfma_x when the train set was matched in several chunks: folds the chunk partials of a query
+ * (n_chunks >= 1; 0 = they have been folded into the output arrays already, by k_match_merge_wide in raw mode), then
+ * recomputes the distances of the query to the other rows of the best row's GROUP (mx_select: MX_RUNS runs of four consecutive
+ * rows) -- the only rows the partials' second best does not cover -- and applies the acceptance test.
+ * Four lanes per query, lane g < MX_RUNS with run g of the group (4 ROWB contiguous bytes).  The rows are read
+ * as packed descriptors where the caller has them (32 bytes: a quarter of the traffic), else as the matcher's operand rows:
+ * 128 bytes of FP4 +1 (0x2) / -1 (0xA) nibbles, two rows differ in a bit where the nibbles' sign bits differ. */
 template <int ROWB>
 __global__ __launch_bounds__(256) void k_match_finish_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
                                                         const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr, int nq_fixed,
@@ -2748,11 +2834,9 @@ __global__ __launch_bounds__(256) void k_match_finish_x(const uint8_t *__restric
                                                         int rnum, int rden, int out_stride, int32_t *__restrict__ idx_out,
                                                         uint16_t *__restrict__ d1_out, uint16_t *__restrict__ d2_out)
 {
-    constexpr int LPQ = ROWB / 4;        /* lanes per query: 8 or 32 */
-    constexpr int LPR = ROWB / 16;       /* lanes per row: 2 or 8 */
-    const int frame = blockIdx.y, g = threadIdx.x & (LPQ - 1);
-    const int qi = blockIdx.x * (256 / LPQ) + (threadIdx.x / LPQ);
-    if (qi >= out_stride) return; /* the LPQ lanes of a query leave together */
+    const int frame = blockIdx.y, g = threadIdx.x & 3;
+    const int qi = blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (qi >= out_stride) return; /* a whole quad leaves together */
     int tframe = frame + train_frame_shift;
     if (tframe < 0) tframe = 0;
     const int nq = nq_arr ? nq_arr[frame] : nq_fixed;
@@ -2773,29 +2857,31 @@ __global__ __launch_bounds__(256) void k_match_finish_x(const uint8_t *__restric
     const bool qvalid = qi < nq;
     int cand = 0xFFFF;
     if (qvalid && j1 >= 0) {
-        const int row = (j1 & ~3) + g / LPR;
+        const int base = mx_group_base(j1) + 8 * g; /* rows base .. base + 3: this lane's run (lanes g >= MX_RUNS have none) */
+        const uint4 *q = (const uint4 *)(query_x + (size_t)frame * q_frame_stride + (size_t)qi * ROWB);
+        const uint4 *t = (const uint4 *)(train_x + (size_t)tframe * t_frame_stride + (size_t)base * ROWB);
         const uint32_t mask = ROWB == SS_X_ROW ? 0x88888888u : 0xFFFFFFFFu;
-        const uint4 a = *(const uint4 *)(query_x + (size_t)frame * q_frame_stride + (size_t)qi * ROWB + 16 * (g & (LPR - 1)));
-        /* rows past the train set are not allocated everywhere */
-        const uint4 b = row < nt ? *(const uint4 *)(train_x + (size_t)tframe * t_frame_stride + (size_t)row * ROWB + 16 * (g & (LPR - 1))) : a;
-        int h = __builtin_popcount((a.x ^ b.x) & mask) + __builtin_popcount((a.y ^ b.y) & mask) + __builtin_popcount((a.z ^ b.z) & mask) +
-                __builtin_popcount((a.w ^ b.w) & mask);
-        /* sum over the LPR lanes of the row */
-        h += __builtin_amdgcn_update_dpp(0, h, 0xB1, 0xF, 0xF, false); /* quad_perm [1,0,3,2] */
-        if (LPR == 8) {
-            h += __builtin_amdgcn_update_dpp(0, h, 0x4E, 0xF, 0xF, false);  /* quad_perm [2,3,0,1] */
-            h += __builtin_amdgcn_update_dpp(0, h, 0x141, 0xF, 0xF, false); /* row_half_mirror: the other quad of the 8 */
+        uint4 qa[ROWB / 16];
+#pragma unroll
+        for (int k = 0; k < ROWB / 16; k++) qa[k] = q[k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = base + r;
+            if (row >= nt || g >= MX_RUNS) break; /* rows past the train set are not allocated everywhere */
+            uint32_t h = 0;
+#pragma unroll
+            for (int k = 0; k < ROWB / 16; k++) {
+                const uint4 b = t[r * (ROWB / 16) + k];
+                h = __builtin_popcount((qa[k].x ^ b.x) & mask) + h;
+                h = __builtin_popcount((qa[k].y ^ b.y) & mask) + h;
+                h = __builtin_popcount((qa[k].z ^ b.z) & mask) + h;
+                h = __builtin_popcount((qa[k].w ^ b.w) & mask) + h;
+            }
+            if (row != j1 && !(excl && row == qi)) cand = imin(cand, (int)h);
         }
-        if (row < nt && row != j1 && !(excl && row == qi)) cand = h;
     }
-    /* minimum over the four rows = over the four row slots of the query's lanes */
-    if (LPR == 2) {
-        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x4E, 0xF, 0xF, false));  /* quad_perm [2,3,0,1]: the other row of the quad */
-        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x141, 0xF, 0xF, false)); /* row_half_mirror: the other quad */
-    } else {
-        cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x140, 0xF, 0xF, false)); /* row_mirror: the other 8 of the 16 */
-        cand = imin(cand, (int)__shfl_xor(cand, 16, 64));                                   /* the other 16 of the 32 */
-    }
+    cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0xB1, 0xF, 0xF, false)); /* quad_perm [1,0,3,2] */
+    cand = imin(cand, __builtin_amdgcn_update_dpp(cand, cand, 0x4E, 0xF, 0xF, false)); /* quad_perm [2,3,0,1] */
     d2 = imin(d2, cand);
     if (g != 0) return;
     const bool ok = qvalid && j1 >= 0 && (th < 0 || (d1 <= th && d1 * rden < d2 * rnum));
@@ -3166,14 +3252,21 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
                  int64_t tp_frame_stride)
 {
     dim3 grid(((out_stride + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks * n_frames);
-    hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
-                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial);
+    mx_finish fin{query_p, train_p, qp_frame_stride, tp_frame_stride, th, rnum, rden, idx, d1, d2};
+    if (n_chunks == 1 && query_p && train_p) { /* one launch: the kernel finishes its queries itself */
+        hipLaunchKernelGGL(k_match_mfma_x<true>, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+                           t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial, fin);
+        return;
+    }
+    hipLaunchKernelGGL(k_match_mfma_x<false>, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial, fin);
+    dim3 g2((out_stride + 63) / 64, n_frames);
     if (query_p && train_p) /* the same rows as packed descriptors: the finish reads those */
-        hipLaunchKernelGGL(k_match_finish_x<32>, dim3((out_stride + 31) / 32, n_frames), dim3(256), 0, s, query_p, train_p, nq_arr, nt_arr, nq_fixed, nt_fixed, qp_frame_stride,
+        hipLaunchKernelGGL(k_match_finish_x<32>, g2, dim3(256), 0, s, query_p, train_p, nq_arr, nt_arr, nq_fixed, nt_fixed, qp_frame_stride,
                            tp_frame_stride, train_frame_shift, exclude_self_mode, (const match_partial *)partial, n_chunks, th, rnum, rden, out_stride,
                            idx, d1, d2);
     else
-        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, dim3((out_stride + 7) / 8, n_frames), dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, g2, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
                            t_frame_stride, train_frame_shift, exclude_self_mode, (const match_partial *)partial, n_chunks, th, rnum, rden, out_stride,
                            idx, d1, d2);
 }
@@ -3183,7 +3276,10 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
 int ssk_match_x_batch_chunks(int rows_q, int rows_t, int n_frames, int *chunk_len)
 {
     const int q_groups = ((rows_q + MX_QBLOCK - 1) / MX_QBLOCK) * (n_frames > 0 ? n_frames : 1);
-    int want = (2048 + q_groups / 2) / q_groups;
+    /* two blocks per CU are resident: from 512 query blocks on, one chunk per block (and the fused epilogue: measured 36 us
+     * for 64 x 2000^2 in one launch against 41 + 12 with two chunks and the finishing launch); fewer query blocks are spread
+     * over more chunks */
+    int want = q_groups >= 512 ? 1 : (1024 + q_groups / 2) / q_groups;
     if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) want = atoi(e); /* experiments */
     const int max_chunks = (rows_t + 255) / 256;
     if (want > max_chunks) want = max_chunks;
@@ -3222,19 +3318,25 @@ void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uin
                         const uint8_t *query_p, const uint8_t *train_p)
 {
     dim3 grid(((nq + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks);
-    hipLaunchKernelGGL(k_match_mfma_x, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
-                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial);
+    mx_finish fin{query_p, train_p, 0, 0, th, rnum, rden, idx, d1, d2};
+    if (n_chunks == 1 && query_p && train_p) {
+        hipLaunchKernelGGL(k_match_mfma_x<true>, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
+                           (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial, fin);
+        return;
+    }
+    hipLaunchKernelGGL(k_match_mfma_x<false>, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
+                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial, fin);
     int fin_chunks = n_chunks;
     if (n_chunks >= 32) { /* many chunks: one wave per query folds them (raw: no acceptance test yet), the finish reads the outputs */
         hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, -1, 1, 1, nq, idx, d1, d2);
         fin_chunks = 0;
     }
     if (query_p && train_p)
-        hipLaunchKernelGGL(k_match_finish_x<32>, dim3((nq + 31) / 32, 1), dim3(256), 0, s, query_p, train_p, (const int32_t *)nullptr,
+        hipLaunchKernelGGL(k_match_finish_x<32>, dim3((nq + 63) / 64, 1), dim3(256), 0, s, query_p, train_p, (const int32_t *)nullptr,
                            (const int32_t *)nullptr, nq, nt, (int64_t)0, (int64_t)0, 0, exclude_self ? 1 : 0, (const match_partial *)partial,
                            fin_chunks, th, rnum, rden, nq, idx, d1, d2);
     else
-        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, dim3((nq + 7) / 8, 1), dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr,
+        hipLaunchKernelGGL(k_match_finish_x<SS_X_ROW>, dim3((nq + 63) / 64, 1), dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr,
                            (const int32_t *)nullptr, nq, nt, (int64_t)0, (int64_t)0, 0, exclude_self ? 1 : 0, (const match_partial *)partial,
                            fin_chunks, th, rnum, rden, nq, idx, d1, d2);
 }
