@@ -2471,14 +2471,17 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #define MX_INIT_KEY 0x4E800000u /* 2^30 as a float: "nothing seen"; 2^30 - 32 rounds back to 2^30 */
 #define MX_FMT_FP4 4
 #define MX_SCALE_ONE 127       /* E8M0: 2^(x - 127) */
-#define MX_QT 2                /* 32-query tiles per wave */
-#define MX_QBLOCK (32 * MX_QT * 4)
-#ifndef MX_NBUF
-#define MX_NBUF 4 /* LDS ring: the DMA of a tile is issued MX_NBUF - 1 steps before the MFMAs that read it, MX_NBUF - 2 before its fragments are read */
-#endif
-#ifndef MX_WAVES_PER_SIMD
-#define MX_WAVES_PER_SIMD 2
-#endif
+/* Two forms of one kernel (template parameters QT, PIPE):
+ * compact   QT = 1, PIPE = false: a wave owns one 32-query tile, fragments are read and the selection runs inside the step of
+ *           their own tile, LDS ring of three; ~90 registers, five waves per SIMD, blocks of 128 queries.  The form for the
+ *           frames of a batch: its blocks are small and short, so they share the CUs with the other batches' kernels.
+ * pipelined QT = 2, PIPE = true: two query tiles per wave (every fragment feeds two MFMAs, a train tile is copied into LDS once
+ *           per 256 queries), fragments and accumulators double buffered (no LDS latency and no selection between a barrier
+ *           and the MFMAs behind it), ring of four; 214 registers, two waves per SIMD.  The form for a large database that has
+ *           the chip to itself: 2000 x 20 M rows 5.6 -> 3.8 ms.  In the four-batch pipeline it is 6 % SLOWER than the compact
+ *           form although 15 % faster alone: two resident blocks per CU hold most of the register file for 30 us. */
+#define MX_QBLOCK_OF(QT) (32 * (QT) * 4)
+#define MX_NBUF_OF(PIPE) ((PIPE) ? 4 : 3) /* LDS ring: the DMA of a tile is issued NBUF - 1 steps before the MFMAs that read it */
 
 /* A lane's 16 keys are, for one query, four RUNS of four consecutive train rows (registers 4 k .. 4 k + 3 = rows
  * 8 k + 4 half .. + 3 of the tile).  MX_RUNS consecutive runs form a GROUP: the minimum of each group, then the two smallest
@@ -2518,13 +2521,14 @@ struct mx_finish {
     uint16_t *d1_out, *d2_out;
 };
 
-template <bool FUSED> /* one chunk covers the train set: the kernel finishes its queries itself (no partials, no second launch) */
-__global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
+template <bool FUSED, int MX_QT, bool PIPE> /* FUSED: one chunk covers the train set, the kernel finishes its queries itself */
+__global__ __launch_bounds__(256, PIPE ? 2 : 5) void k_match_mfma_x(const uint8_t *__restrict__ query_x, const uint8_t *__restrict__ train_x,
                                                        const int32_t *__restrict__ nq_arr, const int32_t *__restrict__ nt_arr,
                                                        int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride,
                                                        int train_frame_shift, int chunk_len, int n_chunks, int exclude_self_mode,
                                                        int out_stride, match_partial *__restrict__ partial, mx_finish fin)
 {
+    constexpr int MX_NBUF = MX_NBUF_OF(PIPE), MX_QBLOCK = MX_QBLOCK_OF(MX_QT);
     __shared__ __attribute__((aligned(16))) uint8_t tiles[MX_NBUF][MX_BUF];
     /* 1-D grid, XCD-aware: every XCD gets a contiguous run of (frame, chunk, query block) triples, so the blocks that
      * stream the same train rows share one L2 (dealt round-robin, the blocks of a frame would pull its rows through all
@@ -2609,7 +2613,7 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         for (int t = 0; t < MX_NBUF - 1; t++) dma_tile(t, t * MX_BUF, ndma_c);
         int wr_off = (MX_NBUF - 1) * MX_BUF;
         auto sync_step = [&](int t) {
-            mx_wait_vm<NDMA * (MX_NBUF - 3)>();
+            mx_wait_vm<NDMA * (MX_NBUF - 2 - (PIPE ? 1 : 0))>(); /* PIPE: tile t + 1 has landed; else: tile t */
 #if !(defined(MX_EXP) && MX_EXP == 5) /* timing experiment 5: no barrier (races: wrong results) */
             __builtin_amdgcn_s_barrier();
 #endif
@@ -2617,10 +2621,11 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
             dma_tile(t + MX_NBUF - 1, wr_off, ndma_c);
             wr_off = wr_off == (MX_NBUF - 1) * MX_BUF ? 0 : wr_off + MX_BUF;
         };
-        /* tile 0 has landed everywhere before anybody reads it */
-        mx_wait_vm<NDMA * (MX_NBUF - 2)>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (PIPE) { /* tile 0 has landed everywhere before anybody reads it */
+            mx_wait_vm<NDMA * (MX_NBUF - 2)>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         if (!ACTIVE) {
             for (int t = 0; t < n_tiles; t++) sync_step(t);
             return;
@@ -2646,8 +2651,8 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         const int e1 = imin(m0, p_part), e2 = m0 <= p_part ? m1 : n_tiles, e3 = imax(e2, p_part);
         const uint32_t a_base = (uint32_t)(col * MX_PITCH + 16 * half);
         int rd_off = 0;
-        v4i afr[2][4];   /* A fragments of the tile of this step (parity P) and of the next one */
-        v16f acc[2][MX_QT];
+        v4i afr[PIPE ? 2 : 1][4]; /* A fragments of the tile of this step (PIPE: parity P, and of the next one) */
+        v16f acc[PIPE ? 2 : 1][MX_QT];
         auto read_frags = [&](v4i(&a4)[4]) {
             const uint8_t *arow = &tiles[0][0] + (a_base + (uint32_t)rd_off);
             rd_off = rd_off == (MX_NBUF - 1) * MX_BUF ? 0 : rd_off + MX_BUF;
@@ -2659,11 +2664,19 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
             for (int sstep = 0; sstep < 4; sstep++) a4[sstep] = *(const v4i *)(arow + 32 * sstep);
 #endif
         };
+        /* the MFMAs of tile t.  PIPE: the fragments are in registers (a4); compact: each k-step's fragment is read from the
+         * tile's LDS slot right before its MFMAs (four registers live instead of sixteen) */
         auto mfma_tile = [&](int t, const v4i(&a4)[4], v16f(&ac)[MX_QT], auto masked_c) {
             constexpr bool MASKED = decltype(masked_c)::value;
+            const uint8_t *arow = nullptr;
+            if (!PIPE) {
+                arow = &tiles[0][0] + (a_base + (uint32_t)rd_off);
+                rd_off = rd_off == (MX_NBUF - 1) * MX_BUF ? 0 : rd_off + MX_BUF;
+            }
 #pragma unroll
             for (int sstep = 0; sstep < 4; sstep++) {
-                const v8i a = v8i{a4[sstep][0], a4[sstep][1], a4[sstep][2], a4[sstep][3], 0, 0, 0, 0};
+                const v4i f = PIPE ? a4[sstep] : *(const v4i *)(arow + 32 * sstep);
+                const v8i a = v8i{f[0], f[1], f[2], f[3], 0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < MX_QT; u++) {
                     v16f ci = sstep == 0 ? crow : ac[u];
@@ -2698,9 +2711,14 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         auto step = [&](int t, auto p_c, auto masked_c, auto first_c) {
             constexpr int P = decltype(p_c)::value;
             sync_step(t);
-            mfma_tile(t, afr[P], acc[P], masked_c);
-            read_frags(afr[1 - P]); /* tile t + 1 (past the end: a landed slot, never used) */
-            if (!decltype(first_c)::value) select_tile(acc[1 - P]);
+            if (PIPE) {
+                mfma_tile(t, afr[P], acc[P], masked_c);
+                read_frags(afr[1 - P]); /* tile t + 1 (past the end: a landed slot, never used) */
+                if (!decltype(first_c)::value) select_tile(acc[1 - P]);
+            } else { /* compact: everything of tile t inside its own step */
+                mfma_tile(t, afr[0], acc[0], masked_c);
+                select_tile(acc[0]);
+            }
         };
         auto segment = [&](int b, int e, auto masked_c) {
             int t = b;
@@ -2714,7 +2732,7 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
             }
             if (t < e) step(t, std::integral_constant<int, 0>{}, masked_c, std::false_type{});
         };
-        read_frags(afr[0]);
+        if (PIPE) read_frags(afr[0]);
         /* tile 0 has no predecessor to select */
         if (e1 > 0) step(0, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
         else step(0, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
@@ -2722,8 +2740,10 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
         segment(imax(e1, 1), e2, std::true_type{});
         segment(imax(e2, 1), e3, std::false_type{});
         segment(imax(e3, 1), n_tiles, std::true_type{});
-        if (n_tiles & 1) select_tile(acc[0]);
-        else select_tile(acc[1]);
+        if (PIPE) {
+            if (n_tiles & 1) select_tile(acc[0]);
+            else select_tile(acc[PIPE ? 1 : 0]);
+        }
     };
     if (n_tiles > 0) {
         if (active) {
@@ -2769,9 +2789,9 @@ __global__ __launch_bounds__(256, MX_WAVES_PER_SIMD) void k_match_mfma_x(const u
     const int g = lane & 7, slot = lane >> 3;
     const uint8_t *qp = fin.query_p + (size_t)frame * fin.qp_frame_stride;
     const uint8_t *tp = fin.train_p + (size_t)tframe * fin.tp_frame_stride;
-    /* two rounds of four passes: the 20 loads of a round are issued together (one memory round trip per round, not per pass) */
+    /* a round of four passes per query tile: the loads of a round are issued together (one memory round trip per round, not per pass) */
 #pragma unroll
-    for (int round = 0; round < 2; round++) {
+    for (int round = 0; round < MX_QT; round++) {
         int pj1[4], pd1[4], pd2[4];
         uint4 pa[4], pb[4][MX_RUNS];
 #pragma unroll
@@ -3242,24 +3262,60 @@ int ssk_match_chunks(int n_query_max, int n_train_max, int n_frames, int *chunk_
     return (int)(((long)n_train_max + len - 1) / len > 0 ? ((long)n_train_max + len - 1) / len : 1);
 }
 
-/* batch form on expanded descriptors (desc_x of the extraction): same arguments as ssk_match, strides in BYTES.  Two
- * launches: k_match_mfma_x writes one partial per (query, chunk), k_match_finish_x folds them, adds the second best inside
- * the best row's group and applies the acceptance test. */
+/* which form of k_match_mfma_x: the pipelined one (two query tiles per wave, two waves per SIMD) for ONE query set against a
+ * large train set, which has the chip to itself; the compact one (five waves per SIMD, 128-query blocks) for the frames of
+ * a batch and for small sets, which share the chip with the other batches' kernels.  SENDSLAM_MX_FORM=compact|pipelined
+ * overrides (A/B measurements). */
+static bool mx_pipelined(int n_frames, int rows_t)
+{
+    if (const char *e = getenv("SENDSLAM_MX_FORM")) return e[0] == 'p';
+    return n_frames == 1 && rows_t >= 65536;
+}
+
+template <bool FUSED, int QT, bool PIPE>
+static void mx_launch(hipStream_t s, dim3 grid, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr, int nq_fixed,
+                      int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len, int n_chunks,
+                      int exclude_self_mode, int out_stride, void *partial, const mx_finish &fin)
+{
+    hipLaunchKernelGGL((k_match_mfma_x<FUSED, QT, PIPE>), grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
+                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial, fin);
+}
+
+/* the matcher's first launch (or only one, when fused); returns true when the outputs are final */
+static bool mx_match(hipStream_t s, bool pipelined, int n_frames, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr,
+                     const int32_t *nt_arr, int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift,
+                     int chunk_len, int n_chunks, int exclude_self_mode, int out_stride, void *partial, const mx_finish &fin)
+{
+    const int qblock = pipelined ? MX_QBLOCK_OF(2) : MX_QBLOCK_OF(1);
+    dim3 grid(((out_stride + qblock - 1) / qblock) * n_chunks * n_frames);
+    const bool fused = n_chunks == 1 && fin.query_p && fin.train_p; /* one launch: the kernel finishes its queries itself */
+#define MX_GO(F, Q, P)                                                                                                                      \
+    mx_launch<F, Q, P>(s, grid, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride, t_frame_stride, train_frame_shift, chunk_len, \
+                       n_chunks, exclude_self_mode, out_stride, partial, fin)
+    if (pipelined) {
+        if (fused) MX_GO(true, 2, true);
+        else MX_GO(false, 2, true);
+    } else {
+        if (fused) MX_GO(true, 1, false);
+        else MX_GO(false, 1, false);
+    }
+#undef MX_GO
+    return fused;
+}
+
+/* batch form on expanded descriptors (desc_x of the extraction): same arguments as ssk_match, strides in BYTES.  With several
+ * chunks two launches: k_match_mfma_x writes one partial per (query, chunk), k_match_finish_x folds them, adds the second best
+ * inside the best row's group and applies the acceptance test. */
 void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, const int32_t *nq_arr, const int32_t *nt_arr,
                  int nq_fixed, int nt_fixed, int64_t q_frame_stride, int64_t t_frame_stride, int train_frame_shift, int chunk_len,
                  int n_chunks, int exclude_self_mode, int th, int rnum, int rden, int out_stride, void *partial, int32_t *idx,
                  uint16_t *d1, uint16_t *d2, int n_frames, const uint8_t *query_p, const uint8_t *train_p, int64_t qp_frame_stride,
                  int64_t tp_frame_stride)
 {
-    dim3 grid(((out_stride + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks * n_frames);
     mx_finish fin{query_p, train_p, qp_frame_stride, tp_frame_stride, th, rnum, rden, idx, d1, d2};
-    if (n_chunks == 1 && query_p && train_p) { /* one launch: the kernel finishes its queries itself */
-        hipLaunchKernelGGL(k_match_mfma_x<true>, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
-                           t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial, fin);
+    if (mx_match(s, mx_pipelined(n_frames, out_stride), n_frames, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride, t_frame_stride,
+                 train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, partial, fin))
         return;
-    }
-    hipLaunchKernelGGL(k_match_mfma_x<false>, grid, dim3(256), 0, s, query_x, train_x, nq_arr, nt_arr, nq_fixed, nt_fixed, q_frame_stride,
-                       t_frame_stride, train_frame_shift, chunk_len, n_chunks, exclude_self_mode, out_stride, (match_partial *)partial, fin);
     dim3 g2((out_stride + 63) / 64, n_frames);
     if (query_p && train_p) /* the same rows as packed descriptors: the finish reads those */
         hipLaunchKernelGGL(k_match_finish_x<32>, g2, dim3(256), 0, s, query_p, train_p, nq_arr, nt_arr, nq_fixed, nt_fixed, qp_frame_stride,
@@ -3271,15 +3327,15 @@ void ssk_match_x(hipStream_t s, const uint8_t *query_x, const uint8_t *train_x, 
                            idx, d1, d2);
 }
 
-/* chunk plan of a batch: rows_q query rows and rows_t train rows per frame.  About 2000 blocks of 256 queries x one chunk of
- * >= 8 tiles */
+/* chunk plan: rows_q query rows and rows_t train rows per frame.  Once the query blocks alone fill the chip, one chunk per
+ * block (and the fused epilogue); fewer query blocks are spread over more chunks of >= 8 tiles. */
 int ssk_match_x_batch_chunks(int rows_q, int rows_t, int n_frames, int *chunk_len)
 {
-    const int q_groups = ((rows_q + MX_QBLOCK - 1) / MX_QBLOCK) * (n_frames > 0 ? n_frames : 1);
-    /* two blocks per CU are resident: from 512 query blocks on, one chunk per block (and the fused epilogue: measured 36 us
-     * for 64 x 2000^2 in one launch against 41 + 12 with two chunks and the finishing launch); fewer query blocks are spread
-     * over more chunks */
-    int want = q_groups >= 512 ? 1 : (1024 + q_groups / 2) / q_groups;
+    const bool pipelined = mx_pipelined(n_frames, rows_t);
+    const int qblock = pipelined ? MX_QBLOCK_OF(2) : MX_QBLOCK_OF(1);
+    const int q_groups = ((rows_q + qblock - 1) / qblock) * (n_frames > 0 ? n_frames : 1);
+    const int fill = pipelined ? 512 : 1024; /* resident blocks: 2 resp. 5 per CU */
+    int want = q_groups >= fill ? 1 : (2 * fill + q_groups / 2) / q_groups;
     if (const char *e = getenv("SENDSLAM_MX_CHUNKS")) want = atoi(e); /* experiments */
     const int max_chunks = (rows_t + 255) / 256;
     if (want > max_chunks) want = max_chunks;
@@ -3317,15 +3373,9 @@ void ssk_match_x_single(hipStream_t s, const uint8_t *query_x, int nq, const uin
                         int exclude_self, int th, int rnum, int rden, void *partial, int32_t *idx, uint16_t *d1, uint16_t *d2,
                         const uint8_t *query_p, const uint8_t *train_p)
 {
-    dim3 grid(((nq + MX_QBLOCK - 1) / MX_QBLOCK) * n_chunks);
     mx_finish fin{query_p, train_p, 0, 0, th, rnum, rden, idx, d1, d2};
-    if (n_chunks == 1 && query_p && train_p) {
-        hipLaunchKernelGGL(k_match_mfma_x<true>, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
-                           (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial, fin);
+    if (mx_match(s, mx_pipelined(1, nt), 1, query_x, train_x, nullptr, nullptr, nq, nt, 0, 0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, partial, fin))
         return;
-    }
-    hipLaunchKernelGGL(k_match_mfma_x<false>, grid, dim3(256), 0, s, query_x, train_x, (const int32_t *)nullptr, (const int32_t *)nullptr, nq, nt,
-                       (int64_t)0, (int64_t)0, 0, chunk_len, n_chunks, exclude_self ? 1 : 0, nq, (match_partial *)partial, fin);
     int fin_chunks = n_chunks;
     if (n_chunks >= 32) { /* many chunks: one wave per query folds them (raw: no acceptance test yet), the finish reads the outputs */
         hipLaunchKernelGGL(k_match_merge_wide, dim3(nq), dim3(64), 0, s, (const match_partial *)partial, nq, n_chunks, -1, 1, 1, nq, idx, d1, d2);
