@@ -353,7 +353,7 @@ typedef struct {
     const int32_t *level_counts;  /* [n_frames][SS_MAX_LEVELS] */
     const ss_keypoint *keypoints; /* [n_frames][kp_capacity] */
     const uint8_t *descriptors;   /* [n_frames][kp_capacity][32] */
-    const int32_t *match_idx;     /* [n_frames][kp_capacity], NULL when match_mode < 0 */
+    const int32_t *match_idx;     /* [n_frames][kp_capacity], NULL when match_mode < 0; match_mode 1: all -1 for a frame whose train frame (the one before) is bad */
     const uint16_t *match_d1, *match_d2;
     const void *d_descriptors;    /* DEVICE copy of `descriptors` (same layout), valid until ss_pipe_release */
 } ss_pipe_result;
@@ -368,7 +368,8 @@ int ss_pipe_acquire(ss_pipe *pipe, ss_pipe_slot *out);
 /* camera_ids / timestamps: n_frames entries each, or NULL (camera 1, timestamp 0) */
 int ss_pipe_submit(ss_pipe *pipe, int slot, int n_frames, const int32_t *camera_ids, const double *timestamps);
 /* frames[i]: caller-owned host image of the pipe's shape with rows of row_stride bytes (NULL = a bad frame);
- * consumed before the call returns.  SS_ERR_BUSY when no slot is free. */
+ * consumed before the call returns.  SS_ERR_BUSY when no slot is free (ss_pipe_last_error is not updated for SS_ERR_BUSY:
+ * producers poll it). */
 int ss_pipe_submit_frames(ss_pipe *pipe, const uint8_t *const *frames, int n_frames, int64_t row_stride,
                           const int32_t *camera_ids, const double *timestamps);
 /* oldest submitted batch: wait blocks until it has completed; poll returns 1 (completed, *out filled), 0 (still
@@ -378,6 +379,10 @@ int ss_pipe_poll(ss_pipe *pipe, ss_pipe_result *out);
 int ss_pipe_release(ss_pipe *pipe, int slot);
 /* batches submitted and not yet returned by wait / poll */
 int ss_pipe_in_flight(const ss_pipe *pipe);
+/* Test hook: the next submission fails (SS_ERR_HIP, "injected failure ...") after `after_operations` of its enqueues have
+ * been issued.  A submission that fails half-way drains its streams before it returns, leaves the slot ACQUIRED (release or
+ * resubmit it) and the pipe usable; ss_pipe_submit_frames frees its slot itself. */
+int ss_pipe_debug_inject_failure(ss_pipe *pipe, int after_operations);
 
 #ifdef __cplusplus
 }

@@ -237,6 +237,7 @@ int ensure_geometry(ss_ctx *c, int w, int h)
          * Off by default: alone it takes the same 0.126 ms per 64 frames, with four batches in flight it costs 7.6 % frames/s
          * (31 KB of LDS per block and 10 % more instructions for the overlapping windows) */
         const char *e = getenv("SENDSLAM_RESIZE_PAIRS");
+        std::fill(std::begin(c->resize_pair), std::end(c->resize_pair), false); /* flags of the previous geometry do not survive */
         for (int l = 1; l + 1 < g.n_levels && e && atoi(e);)
             if (ssk_resize_pair_fits(g, c->tabs.rtab.data(), l)) { c->resize_pair[l] = true; l += 2; } else l += 1;
     }

@@ -2614,6 +2614,12 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void k_match_mfma_x(const uint8_
         int wr_off = (MX_NBUF - 1) * MX_BUF;
         auto sync_step = [&](int t) {
             mx_wait_vm<NDMA * (MX_NBUF - 2 - (PIPE ? 1 : 0))>(); /* PIPE: tile t + 1 has landed; else: tile t */
+            /* every LDS read this wave has issued is complete before it arrives: the compiler otherwise lets the last fragment
+             * read of a tile (and the MFMA behind it) sink below the barrier, and the DMA another wave issues right after the
+             * barrier refills exactly that slot */
+#if !(defined(MX_EXP) && MX_EXP == 7) /* experiment 7: the hazard itself (profiles/tools/repro_partial.py shows the wrong partials) */
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #if !(defined(MX_EXP) && MX_EXP == 5) /* timing experiment 5: no barrier (races: wrong results) */
             __builtin_amdgcn_s_barrier();
 #endif

@@ -145,25 +145,47 @@ struct ss_pipe {
     std::deque<int> in_flight; /* slot ids in submission order */
     uint64_t next_sequence = 0;
     mutable std::mutex m;
-    std::string err;
+    /* last error of the producer calls (acquire, submit*) and of the consumer calls (wait, poll, release): one thread each may
+     * use the pipe at the same time, so each side owns its string; ss_pipe_last_error returns the younger one */
+    std::string err_producer, err_consumer;
+    std::atomic<int> err_side{0}; /* 0 none, 1 producer, 2 consumer */
+    bool broken = false;        /* a submission failed half-way and its streams could not be drained */
+    int inject_fail_after = -1; /* test hook (ss_pipe_debug_inject_failure): the next submission fails after this many enqueued operations */
     copy_pool *pool = nullptr;
 };
 
 namespace {
 
-int pfail(ss_pipe *p, int code, const std::string &msg)
+enum { SIDE_PRODUCER = 1, SIDE_CONSUMER = 2 };
+
+int pfail(ss_pipe *p, int code, const std::string &msg, int side = SIDE_PRODUCER)
 {
-    if (p) p->err = msg;
-    else g_pipe_create_error = msg;
+    if (!p) {
+        g_pipe_create_error = msg;
+        return code;
+    }
+    (side == SIDE_CONSUMER ? p->err_consumer : p->err_producer) = msg;
+    p->err_side.store(side, std::memory_order_release);
     return code;
 }
 
-#define PIPE_HIP(p, call)                                                                                       \
+#define PIPE_HIP_SIDE(p, call, side)                                                                            \
     do {                                                                                                        \
         hipError_t e_ = (call);                                                                                 \
         if (e_ != hipSuccess)                                                                                   \
             return pfail((p), e_ == hipErrorOutOfMemory ? SS_ERR_NO_MEMORY : SS_ERR_HIP,                        \
-                         std::string(#call) + ": " + hipGetErrorString(e_));                                    \
+                         std::string(#call) + ": " + hipGetErrorString(e_), (side));                            \
+    } while (0)
+#define PIPE_HIP(p, call) PIPE_HIP_SIDE(p, call, SIDE_PRODUCER)
+/* an enqueue of a submission: counts towards the injected failure of the test hook */
+#define PIPE_ENQ(p, call)                                                                                       \
+    do {                                                                                                        \
+        if ((p)->inject_fail_after == 0) {                                                                      \
+            (p)->inject_fail_after = -1;                                                                        \
+            return pfail((p), SS_ERR_HIP, "injected failure before " #call);                                    \
+        }                                                                                                       \
+        if ((p)->inject_fail_after > 0) (p)->inject_fail_after--;                                               \
+        PIPE_HIP(p, call);                                                                                      \
     } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -194,6 +216,12 @@ void fill_result(ss_pipe *p, pipe_slot &s, int id, ss_pipe_result *out)
                 for (int k = 0; k < p->kcap; k++) s.h_midx[(size_t)i * p->kcap + k] = -1;
         }
     }
+    /* match_mode 1: frame i was matched against frame i - 1's rows; when that frame is bad its rows are not reported, so
+     * frame i's indices would point nowhere */
+    if (p->cfg.match_mode == 1 && s.h_midx)
+        for (int i = 1; i < s.n_frames; i++)
+            if (s.status[i - 1] != SS_OK)
+                for (int k = 0; k < p->kcap; k++) s.h_midx[(size_t)i * p->kcap + k] = -1;
     out->slot = id;
     out->n_frames = s.n_frames;
     out->kp_capacity = p->kcap;
@@ -215,7 +243,18 @@ void fill_result(ss_pipe *p, pipe_slot &s, int id, ss_pipe_result *out)
 
 extern "C" {
 
-const char *ss_pipe_last_error(const ss_pipe *p) { return p ? p->err.c_str() : g_pipe_create_error.c_str(); }
+const char *ss_pipe_last_error(const ss_pipe *p)
+{
+    if (!p) return g_pipe_create_error.c_str();
+    return p->err_side.load(std::memory_order_acquire) == SIDE_CONSUMER ? p->err_consumer.c_str() : p->err_producer.c_str();
+}
+
+int ss_pipe_debug_inject_failure(ss_pipe *p, int after_operations)
+{
+    if (!p) return SS_ERR_INVALID_ARG;
+    p->inject_fail_after = after_operations;
+    return SS_OK;
+}
 
 int ss_pipe_destroy(ss_pipe *p)
 {
@@ -265,7 +304,7 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
     const size_t pix_bytes = (size_t)p->frame_stride * c.batch;
 
     auto bail = [&](int code) {
-        const std::string msg = p->err;
+        const std::string msg = p->err_producer;
         ss_pipe_destroy(p);
         g_pipe_create_error = msg;
         return code;
@@ -275,13 +314,13 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
         pipe_slot &s = p->slots[(size_t)i];
         int rc = ss_create(device_ordinal, &prm, &s.ctx);
         if (rc != SS_OK) {
-            p->err = ss_last_error(nullptr);
+            p->err_producer = ss_last_error(nullptr);
             return bail(rc);
         }
         if (cam) {
             rc = ss_set_calibration(s.ctx, 1, cam);
             if (rc != SS_OK) {
-                p->err = ss_last_error(s.ctx);
+                p->err_producer = ss_last_error(s.ctx);
                 return bail(rc);
             }
         }
@@ -295,7 +334,7 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_pix, pix_bytes);
         if (e == hipSuccess) e = hipMemsetAsync(s.d_pix, 0, pix_bytes, s.stream);
         if (e != hipSuccess) {
-            p->err = std::string("ss_pipe_create: ") + hipGetErrorString(e);
+            p->err_producer = std::string("ss_pipe_create: ") + hipGetErrorString(e);
             return bail(e == hipErrorOutOfMemory ? SS_ERR_NO_MEMORY : SS_ERR_HIP);
         }
         memset(s.h_pix, 0, pix_bytes);
@@ -305,7 +344,7 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
         if (rc == SS_OK) rc = ss_synchronize(s.ctx);
         if (rc == SS_OK) rc = ss_get_batch_view(s.ctx, &s.view);
         if (rc != SS_OK) {
-            p->err = ss_last_error(s.ctx);
+            p->err_producer = ss_last_error(s.ctx);
             return bail(rc);
         }
         p->kcap = s.view.kp_capacity;
@@ -323,7 +362,7 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
         e = hipHostMalloc((void **)&s.h_res, off, hipHostMallocDefault);
         if (e == hipSuccess && c.match_mode >= 0) e = hipMalloc((void **)&s.d_match, B * K * 8);
         if (e != hipSuccess) {
-            p->err = std::string("ss_pipe_create: ") + hipGetErrorString(e);
+            p->err_producer = std::string("ss_pipe_create: ") + hipGetErrorString(e);
             return bail(e == hipErrorOutOfMemory ? SS_ERR_NO_MEMORY : SS_ERR_HIP);
         }
         memset(s.h_res, 0, off);
@@ -342,7 +381,7 @@ int ss_pipe_create(int device_ordinal, const ss_orb_params *params, const ss_cam
                                        s.d_match + B * K * 6);
             if (rc == SS_OK) rc = ss_synchronize(s.ctx);
             if (rc != SS_OK) {
-                p->err = ss_last_error(s.ctx);
+                p->err_producer = ss_last_error(s.ctx);
                 return bail(rc);
             }
         }
@@ -369,7 +408,41 @@ int ss_pipe_acquire(ss_pipe *p, ss_pipe_slot *out)
         out->frame_stride = p->frame_stride;
         return SS_OK;
     }
-    return pfail(p, SS_ERR_BUSY, "ss_pipe_acquire: every slot is in flight or not yet released");
+    /* polled in a loop by producers: no message is formatted (ss_pipe_last_error is not updated for SS_ERR_BUSY) */
+    return p->broken ? pfail(p, SS_ERR_STATE, "ss_pipe: a failed submission could not be drained; destroy the pipe") : SS_ERR_BUSY;
+}
+
+/* the enqueues of one submission, on the upload stream and on the slot's stream */
+static int enqueue_batch(ss_pipe *p, pipe_slot &s, int n)
+{
+    const ss_pipe_config &c = p->cfg;
+    const size_t K = (size_t)p->kcap, N = (size_t)n;
+    PIPE_ENQ(p, hipMemcpyAsync(s.d_pix, s.h_pix, (size_t)p->frame_stride * N, hipMemcpyHostToDevice, p->upload));
+    PIPE_ENQ(p, hipEventRecord(s.uploaded, p->upload));
+    PIPE_ENQ(p, hipStreamWaitEvent(s.stream, s.uploaded, 0));
+    if (p->inject_fail_after == 0) {
+        p->inject_fail_after = -1;
+        return pfail(p, SS_ERR_HIP, "injected failure before ss_extract_batch_device");
+    }
+    if (p->inject_fail_after > 0) p->inject_fail_after--;
+    int rc = ss_extract_batch_device(s.ctx, s.d_pix, n, c.width, c.height, c.channels, p->row_stride, p->frame_stride);
+    if (rc != SS_OK) return pfail(p, rc, ss_last_error(s.ctx));
+    if (c.match_mode >= 0) {
+        uint8_t *dm = s.d_match;
+        const size_t B = (size_t)c.batch;
+        rc = ss_match_batch_device(s.ctx, c.match_mode, c.match_th, c.ratio_num, c.ratio_den, dm, dm + B * K * 4, dm + B * K * 6);
+        if (rc != SS_OK) return pfail(p, rc, ss_last_error(s.ctx));
+        PIPE_ENQ(p, hipMemcpyAsync(s.h_midx, dm, N * K * 4, hipMemcpyDeviceToHost, s.stream));
+        PIPE_ENQ(p, hipMemcpyAsync(s.h_md1, dm + B * K * 4, N * K * 2, hipMemcpyDeviceToHost, s.stream));
+        PIPE_ENQ(p, hipMemcpyAsync(s.h_md2, dm + B * K * 6, N * K * 2, hipMemcpyDeviceToHost, s.stream));
+    }
+    PIPE_ENQ(p, hipMemcpyAsync(s.h_nkp, s.view.n_keypoints, N * 4, hipMemcpyDeviceToHost, s.stream));
+    PIPE_ENQ(p, hipMemcpyAsync(s.h_levels, s.view.level_counts, N * SS_MAX_LEVELS * 4, hipMemcpyDeviceToHost, s.stream));
+    PIPE_ENQ(p, hipMemcpyAsync(s.h_err, s.view.frame_error, N * 4, hipMemcpyDeviceToHost, s.stream));
+    PIPE_ENQ(p, hipMemcpyAsync(s.h_kps, s.view.keypoints, N * K * sizeof(ss_keypoint), hipMemcpyDeviceToHost, s.stream));
+    PIPE_ENQ(p, hipMemcpyAsync(s.h_desc, s.view.descriptors, N * K * SS_DESC_BYTES, hipMemcpyDeviceToHost, s.stream));
+    PIPE_ENQ(p, hipEventRecord(s.done, s.stream));
+    return SS_OK;
 }
 
 /* caller holds no lock; slot must be ACQUIRED.  status[] may already carry producer-side errors. */
@@ -379,11 +452,11 @@ static int submit_locked(ss_pipe *p, int slot, int n, const int32_t *camera_ids,
     pipe_slot &s = p->slots[(size_t)slot];
     {
         std::lock_guard<std::mutex> g(p->m);
+        if (p->broken) return pfail(p, SS_ERR_STATE, "ss_pipe: a failed submission could not be drained; destroy the pipe");
         if (s.state != SLOT_ACQUIRED) return pfail(p, SS_ERR_STATE, "ss_pipe_submit: slot was not acquired");
     }
     if (n < 1 || n > p->cfg.batch) return pfail(p, SS_ERR_INVALID_ARG, "ss_pipe_submit: n_frames out of range (1..batch)");
     (void)hipSetDevice(p->device);
-    const ss_pipe_config &c = p->cfg;
     for (int i = 0; i < n; i++) {
         if (!keep_status) s.status[(size_t)i] = SS_OK;
         s.camera_id[(size_t)i] = camera_ids ? camera_ids[i] : 1;
@@ -392,27 +465,20 @@ static int submit_locked(ss_pipe *p, int slot, int n, const int32_t *camera_ids,
         if (s.camera_id[(size_t)i] == 0) s.status[(size_t)i] = SS_ERR_BAD_FRAME;
     }
     s.n_frames = n;
-    const size_t K = (size_t)p->kcap, N = (size_t)n;
-    PIPE_HIP(p, hipMemcpyAsync(s.d_pix, s.h_pix, (size_t)p->frame_stride * N, hipMemcpyHostToDevice, p->upload));
-    PIPE_HIP(p, hipEventRecord(s.uploaded, p->upload));
-    PIPE_HIP(p, hipStreamWaitEvent(s.stream, s.uploaded, 0));
-    int rc = ss_extract_batch_device(s.ctx, s.d_pix, n, c.width, c.height, c.channels, p->row_stride, p->frame_stride);
-    if (rc != SS_OK) return pfail(p, rc, ss_last_error(s.ctx));
-    if (c.match_mode >= 0) {
-        uint8_t *dm = s.d_match;
-        const size_t B = (size_t)c.batch;
-        rc = ss_match_batch_device(s.ctx, c.match_mode, c.match_th, c.ratio_num, c.ratio_den, dm, dm + B * K * 4, dm + B * K * 6);
-        if (rc != SS_OK) return pfail(p, rc, ss_last_error(s.ctx));
-        PIPE_HIP(p, hipMemcpyAsync(s.h_midx, dm, N * K * 4, hipMemcpyDeviceToHost, s.stream));
-        PIPE_HIP(p, hipMemcpyAsync(s.h_md1, dm + B * K * 4, N * K * 2, hipMemcpyDeviceToHost, s.stream));
-        PIPE_HIP(p, hipMemcpyAsync(s.h_md2, dm + B * K * 6, N * K * 2, hipMemcpyDeviceToHost, s.stream));
+    const int rc = enqueue_batch(p, s, n);
+    if (rc != SS_OK) {
+        /* part of the batch may be enqueued (the upload, kernels, some result copies) and still use h_pix, d_pix and h_res:
+         * both streams are drained before the slot can be handed out again; if even that fails the pipe refuses further
+         * work.  The slot stays ACQUIRED: the caller releases or resubmits it. */
+        const std::string first = p->err_producer;
+        const hipError_t e1 = hipStreamSynchronize(p->upload), e2 = hipStreamSynchronize(s.stream);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            std::lock_guard<std::mutex> g(p->m);
+            p->broken = true;
+        }
+        (void)hipGetLastError();
+        return pfail(p, rc, first);
     }
-    PIPE_HIP(p, hipMemcpyAsync(s.h_nkp, s.view.n_keypoints, N * 4, hipMemcpyDeviceToHost, s.stream));
-    PIPE_HIP(p, hipMemcpyAsync(s.h_levels, s.view.level_counts, N * SS_MAX_LEVELS * 4, hipMemcpyDeviceToHost, s.stream));
-    PIPE_HIP(p, hipMemcpyAsync(s.h_err, s.view.frame_error, N * 4, hipMemcpyDeviceToHost, s.stream));
-    PIPE_HIP(p, hipMemcpyAsync(s.h_kps, s.view.keypoints, N * K * sizeof(ss_keypoint), hipMemcpyDeviceToHost, s.stream));
-    PIPE_HIP(p, hipMemcpyAsync(s.h_desc, s.view.descriptors, N * K * SS_DESC_BYTES, hipMemcpyDeviceToHost, s.stream));
-    PIPE_HIP(p, hipEventRecord(s.done, s.stream));
     {
         std::lock_guard<std::mutex> g(p->m);
         s.state = SLOT_IN_FLIGHT;
@@ -474,17 +540,17 @@ static int take_oldest(ss_pipe *p, bool block, ss_pipe_result *out)
     int id;
     {
         std::lock_guard<std::mutex> g(p->m);
-        if (p->in_flight.empty()) return block ? pfail(p, SS_ERR_STATE, "ss_pipe_wait: nothing has been submitted") : 0;
+        if (p->in_flight.empty()) return block ? pfail(p, SS_ERR_STATE, "ss_pipe_wait: nothing has been submitted", SIDE_CONSUMER) : 0;
         id = p->in_flight.front();
     }
     pipe_slot &s = p->slots[(size_t)id];
     (void)hipSetDevice(p->device);
     if (block) {
-        PIPE_HIP(p, hipEventSynchronize(s.done));
+        PIPE_HIP_SIDE(p, hipEventSynchronize(s.done), SIDE_CONSUMER);
     } else {
         const hipError_t e = hipEventQuery(s.done);
         if (e == hipErrorNotReady) return 0;
-        if (e != hipSuccess) return pfail(p, SS_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+        if (e != hipSuccess) return pfail(p, SS_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e), SIDE_CONSUMER);
     }
     {
         std::lock_guard<std::mutex> g(p->m);
@@ -502,9 +568,10 @@ int ss_pipe_release(ss_pipe *p, int slot)
 {
     if (!p) return SS_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(p->m);
-    if (slot < 0 || slot >= (int)p->slots.size()) return pfail(p, SS_ERR_INVALID_ARG, "ss_pipe_release: no such slot");
+    if (slot < 0 || slot >= (int)p->slots.size()) return pfail(p, SS_ERR_INVALID_ARG, "ss_pipe_release: no such slot", SIDE_CONSUMER);
     pipe_slot &s = p->slots[(size_t)slot];
-    if (s.state != SLOT_RETURNED && s.state != SLOT_ACQUIRED) return pfail(p, SS_ERR_STATE, "ss_pipe_release: slot is free or still in flight");
+    if (s.state != SLOT_RETURNED && s.state != SLOT_ACQUIRED)
+        return pfail(p, SS_ERR_STATE, "ss_pipe_release: slot is free or still in flight", SIDE_CONSUMER);
     s.state = SLOT_FREE;
     return SS_OK;
 }

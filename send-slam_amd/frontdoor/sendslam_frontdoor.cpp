@@ -322,8 +322,8 @@ int main(int argc, char **argv)
     const bool emitFeatures = env_int("SENDSLAM_EMIT_FEATURES", 0) != 0;
 
     ss_ctx *ctx = nullptr;
-    vector<float> vTimesTrack;
-    double previousTimestamp = -1.0;
+    vector<float> trackSeconds;
+    double lastFrameStamp = -1.0;
 
     cout << endl << "-------" << endl;
     cout << "Connecting to tcp://127.0.0.1:" << port << " ..." << endl;
@@ -356,7 +356,7 @@ int main(int argc, char **argv)
     };
 
     constexpr size_t kMaxMessageSize = 50 * 1024 * 1024; /* 50 MB safety guard (:412) */
-    bool calibrationReceived = false;
+    bool haveCalibration = false;
     int exitCode = 0;
     vector<uint8_t> payload, pix;
 
@@ -395,14 +395,22 @@ int main(int argc, char **argv)
     vector<double> openStamps;
     vector<chrono::steady_clock::time_point> submitTimes; /* per batch in flight, oldest first */
 
-    /* takes the oldest completed batch (blocking), tracks its frames in order, ships poses */
-    auto finish_batch = [&]() {
+    /* A pipe call that fails for a reason other than a bad frame (a HIP error: the GPU or its driver is in trouble) ends
+     * the process with a non-zero code, so that the supervisor starts a fresh backend (docker_handler.ex:117-145 stops itself
+     * on a dead container for exactly that).  Carrying on would mean polling slots that can never complete. */
+    bool pipeFailed = false;
+    auto pipe_fatal = [&](const char *what) {
+        cerr << "GPU pipeline failed (" << what << "): " << ss_pipe_last_error(pipe) << " -- exiting for a supervised restart" << endl;
+        pipeFailed = true;
+        exitCode = 3;
+    };
+    /* takes the oldest completed batch (blocking), tracks its frames in order, ships poses; false = the pipe has failed */
+    auto finish_batch = [&]() -> bool {
         ss_pipe_result r{};
+        if (pipeFailed || batchesInFlight <= 0 || submitTimes.empty()) return false;
         if (ss_pipe_wait(pipe, &r) != SS_OK) {
-            cerr << "Frame batch lost: " << ss_pipe_last_error(pipe) << endl;
-            batchesInFlight = 0;
-            submitTimes.clear();
-            return;
+            pipe_fatal("ss_pipe_wait");
+            return false;
         }
         const double extractShare = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - submitTimes.front()).count() / max(1, r.n_frames);
         submitTimes.erase(submitTimes.begin());
@@ -423,15 +431,19 @@ int main(int argc, char **argv)
             }
             emit_tracked(tracked, r.camera_id[i], r.timestamp[i]);
             const double ttrack = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - t1).count();
-            vTimesTrack.push_back((float)(ttrack + extractShare));
+            trackSeconds.push_back((float)(ttrack + extractShare));
         }
         ss_pipe_release(pipe, r.slot);
+        return true;
     };
     auto submit_open = [&]() {
         if (!pipe || openN == 0) return;
-        if (ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()) != SS_OK) {
-            cerr << "Frame batch skipped: " << ss_pipe_last_error(pipe) << endl;
-            ss_pipe_release(pipe, openSlot.slot);
+        /* test hook: SENDSLAM_TEST_PIPE_FAIL_BATCH=n makes the n-th submission of this process fail half-way */
+        static int submissions = 0;
+        if (env_int("SENDSLAM_TEST_PIPE_FAIL_BATCH", -1) == submissions++) ss_pipe_debug_inject_failure(pipe, 4);
+        if (pipeFailed) {
+        } else if (ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()) != SS_OK) {
+            pipe_fatal("ss_pipe_submit");
         } else {
             batchesInFlight++;
             submitTimes.push_back(chrono::steady_clock::now());
@@ -443,10 +455,10 @@ int main(int argc, char **argv)
     /* everything received so far is tracked and answered before the caller goes on (other message types, EOF, idle socket) */
     auto drain_pipe = [&]() {
         submit_open();
-        while (pipe && batchesInFlight > 0) finish_batch();
+        while (pipe && batchesInFlight > 0 && finish_batch()) {}
     };
     auto destroy_pipe = [&]() {
-        drain_pipe();
+        if (!pipeFailed) drain_pipe();
         if (pipe) ss_pipe_destroy(pipe);
         pipe = nullptr;
     };
@@ -459,6 +471,7 @@ int main(int argc, char **argv)
 
     while (true) {
         if (pipe && (openN > 0 || batchesInFlight > 0) && !input_queued()) drain_pipe(); /* idle socket: answer now */
+        if (pipeFailed) break;
         uint8_t lengthBuffer[4];
         const int r = readExact(lengthBuffer, 4);
         if (r <= 0) drain_pipe();
@@ -503,6 +516,7 @@ int main(int argc, char **argv)
         }
 
         if (packet.type != "frame") drain_pipe(); /* messages are answered in order */
+        if (pipeFailed) break;
         if (packet.type == "terminate" || packet.type == "shutdown") {
             cout << "Received termination request from server." << endl;
             break;
@@ -544,15 +558,15 @@ int main(int argc, char **argv)
             }
             pipeCam = cam;
             if (env_int("SENDSLAM_PRINT_SETTINGS", 0)) cout << settings_text(c, params);
-            calibrationReceived = true;
-            vTimesTrack.clear();
-            previousTimestamp = -1.0;
+            haveCalibration = true;
+            trackSeconds.clear();
+            lastFrameStamp = -1.0;
             cout << "Calibration parameters received. SLAM system ready to process frames." << endl;
             continue;
         }
 
         if (packet.type == "frame") {
-            if (!calibrationReceived) {
+            if (!haveCalibration) {
                 cerr << "Received frame before calibration. Ignoring." << endl;
                 continue;
             }
@@ -594,14 +608,19 @@ int main(int argc, char **argv)
                     pipeW = w; pipeH = h; pipeCh = ch;
                 }
                 if (openN == 0) {
-                    while (ss_pipe_acquire(pipe, &openSlot) == SS_ERR_BUSY) finish_batch();
+                    int arc;
+                    while ((arc = ss_pipe_acquire(pipe, &openSlot)) == SS_ERR_BUSY)
+                        if (!finish_batch()) break; /* every slot busy and nothing can complete: the pipe has failed */
+                    if (arc != SS_OK && !pipeFailed) pipe_fatal("ss_pipe_acquire");
+                    if (pipeFailed) break;
                 }
                 pnm_copy(packet.imageData + pnmOff, w, h, ch, openSlot.pixels + (size_t)openN * openSlot.frame_stride, (size_t)openSlot.row_stride);
                 openCams.push_back(packet.camera_id);
                 openStamps.push_back(packet.timestamp);
                 openN++;
                 if (openN == readAhead || !input_queued()) submit_open();
-                previousTimestamp = packet.timestamp;
+                if (pipeFailed) break;
+                lastFrameStamp = packet.timestamp;
                 continue;
             }
 
@@ -618,13 +637,13 @@ int main(int argc, char **argv)
             emit_tracked(tracked, packet.camera_id, packet.timestamp);
             const auto t2 = chrono::steady_clock::now();
             const double ttrack = chrono::duration_cast<chrono::duration<double>>(t2 - t1).count();
-            vTimesTrack.push_back((float)ttrack);
+            trackSeconds.push_back((float)ttrack);
 
-            if (previousTimestamp > 0.0) { /* never outrun the timestamps (:618-624) */
-                const double interval = packet.timestamp - previousTimestamp;
+            if (lastFrameStamp > 0.0) { /* never outrun the timestamps (:618-624) */
+                const double interval = packet.timestamp - lastFrameStamp;
                 if (ttrack < interval && !noPacing) usleep((useconds_t)((interval - ttrack) * 1e6));
             }
-            previousTimestamp = packet.timestamp;
+            lastFrameStamp = packet.timestamp;
             continue;
         }
 
@@ -636,13 +655,13 @@ int main(int argc, char **argv)
     ::close(fd);
 
     if (ctx) {
-        if (!vTimesTrack.empty()) {
-            sort(vTimesTrack.begin(), vTimesTrack.end());
-            const float totaltime = accumulate(vTimesTrack.begin(), vTimesTrack.end(), 0.0f);
+        if (!trackSeconds.empty()) {
+            sort(trackSeconds.begin(), trackSeconds.end());
+            const float totaltime = accumulate(trackSeconds.begin(), trackSeconds.end(), 0.0f);
             cout << "-------" << endl;
-            cout << "Frames processed: " << vTimesTrack.size() << endl;
-            cout << "median tracking time: " << vTimesTrack[vTimesTrack.size() / 2] << endl;
-            cout << "mean tracking time: " << totaltime / vTimesTrack.size() << endl;
+            cout << "Frames processed: " << trackSeconds.size() << endl;
+            cout << "median tracking time: " << trackSeconds[trackSeconds.size() / 2] << endl;
+            cout << "mean tracking time: " << totaltime / trackSeconds.size() << endl;
         } else {
             cout << "No frames processed." << endl;
         }

@@ -32,7 +32,7 @@ EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy",
            "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
            "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight",
            "ss_match_fold_strided_device", "ss_xchg_create", "ss_xchg_destroy", "ss_xchg_last_error", "ss_xchg_status",
-           "ss_xchg_allgather", "ss_xchg_broadcast"]
+           "ss_xchg_allgather", "ss_xchg_broadcast", "ss_pipe_debug_inject_failure"]
 
 
 class OrbParams(C.Structure):
@@ -185,6 +185,7 @@ def load():
     lib.ss_pipe_poll.argtypes = [C.c_void_p, C.POINTER(PipeResult)]
     lib.ss_pipe_release.argtypes = [C.c_void_p, C.c_int]
     lib.ss_pipe_in_flight.argtypes = [C.c_void_p]
+    lib.ss_pipe_debug_inject_failure.argtypes = [C.c_void_p, C.c_int]
     if lib.ss_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI {lib.ss_abi_version()} != {ABI_VERSION}")
     _lib = lib
@@ -510,8 +511,12 @@ class Pipe:
     def submit_frames(self, frames, camera_ids=None, timestamps=None, row_stride: Optional[int] = None) -> bool:
         """frames: sequence of uint8 arrays of the pipe's shape (None = a bad frame).  False when no slot is free."""
         keep = [None if f is None else np.ascontiguousarray(f, np.uint8) for f in frames]
-        ptrs = (C.c_void_p * len(keep))(*[None if f is None else f.ctypes.data for f in keep])
         rs = self.cfg.width * self.cfg.channels if row_stride is None else row_stride
+        need = (self.cfg.height - 1) * rs + self.cfg.width * self.cfg.channels  # what the library's copy threads read per frame
+        for i, f in enumerate(keep):
+            if f is not None and f.size < need:
+                raise ValueError(f"frame {i}: {f.size} bytes, the pipe's shape needs {need} (height {self.cfg.height}, row stride {rs})")
+        ptrs = (C.c_void_p * len(keep))(*[None if f is None else f.ctypes.data for f in keep])
         ci = None if camera_ids is None else np.ascontiguousarray(camera_ids, np.int32)
         ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
         rc = self._lib.ss_pipe_submit_frames(self._h, ptrs, len(keep), rs, None if ci is None else ci.ctypes.data,
@@ -524,6 +529,9 @@ class Pipe:
     def submit_batch_array(self, batch: np.ndarray, camera_ids=None, timestamps=None) -> bool:
         """batch: one contiguous uint8 array [n, height, width(, channels)]: frame pointers without per-frame Python work"""
         assert batch.dtype == np.uint8 and batch.flags.c_contiguous
+        want = (self.cfg.height, self.cfg.width) if self.cfg.channels == 1 and batch.ndim == 3 else (self.cfg.height, self.cfg.width, self.cfg.channels)
+        if tuple(batch.shape[1:]) != want:
+            raise ValueError(f"batch frames have shape {tuple(batch.shape[1:])}, the pipe's shape is {want}")
         n = batch.shape[0]
         fs = batch.strides[0]
         base = batch.ctypes.data
@@ -565,6 +573,10 @@ class Pipe:
 
     def release(self, slot: int):
         self._check(self._lib.ss_pipe_release(self._h, slot))
+
+    def debug_inject_failure(self, after_operations: int):
+        """test hook: the next submission fails after that many of its enqueues"""
+        self._check(self._lib.ss_pipe_debug_inject_failure(self._h, int(after_operations)))
 
     def in_flight(self) -> int:
         return self._check(self._lib.ss_pipe_in_flight(self._h))

@@ -315,3 +315,92 @@ def test_expanded_operands_match_equals_oracle(oracle, nq, nt):
             ctx.synchronize()
             want = oracle.match(q, q, th=256, ratio_num=10, exclude_self=True)
             assert np.array_equal(idx.cpu().numpy(), want[0]) and np.array_equal(d1.cpu().numpy().view(np.uint16), want[1])
+
+
+def test_submission_that_fails_half_way_drains_and_leaves_the_pipe_usable(oracle):
+    """ss_pipe_debug_inject_failure: the submission fails after k of its enqueues (the upload, the kernels, some result copies
+    may already be in flight).  The library drains the streams before it returns, the slot can be reused at once, and the
+    batches submitted afterwards are bit-exact -- a slot recycled with work still in flight would corrupt them."""
+    w, h, nf, B = 640, 480, 600, 4
+    frames = [synth.frame(900 + i, w, h) for i in range(2 * B)]
+    p = oracle.default_params(n_features=nf)
+    want = [oracle.extract(f, p) for f in frames]
+    with binding.Pipe(0, w, h, batch=B, depth=2, match_mode=0, n_features=nf) as pipe:
+        for after in (0, 1, 3, 4, 6, 9, 12):
+            pipe.debug_inject_failure(after)
+            with pytest.raises(binding.OrbError) as e:
+                pipe.submit_frames(frames[:B])
+            assert "injected failure" in str(e.value)
+            assert pipe.in_flight() == 0
+            # both slots are free again: two real batches go through and come back right
+            assert pipe.submit_frames(frames[:B]) and pipe.submit_frames(frames[B:])
+            for k in range(2):
+                r = pipe.wait()
+                assert (r["status"] == 0).all()
+                for i in range(B):
+                    okps, odesc, _ = want[k * B + i]
+                    check_frame(r, i, okps, odesc, oracle.match(odesc, odesc, exclude_self=True))
+                pipe.release(r["slot"])
+        # explicit slot: the failed submission leaves it ACQUIRED; resubmitting the same slot works
+        sl = pipe.acquire()
+        sl[1][:B, :, :w] = np.stack(frames[:B])
+        pipe.debug_inject_failure(5)
+        with pytest.raises(binding.OrbError):
+            pipe.submit(sl[0], B)
+        pipe.submit(sl[0], B)
+        r = pipe.wait()
+        for i in range(B):
+            check_frame(r, i, want[i][0], want[i][1])
+        pipe.release(r["slot"])
+
+
+def test_match_mode_1_bad_train_frame_gives_no_indices(oracle):
+    """frame b is matched against frame b - 1 of the batch; when that frame is bad (NULL pointer) its rows are not reported, so
+    frame b's indices are all -1; the frames after it are matched as usual"""
+    w, h, nf, B = 640, 480, 600, 4
+    frames = [synth.frame(950 + i, w, h) for i in range(B)]
+    p = oracle.default_params(n_features=nf)
+    want = [oracle.extract(f, p) for f in frames]
+    with binding.Pipe(0, w, h, batch=B, depth=2, match_mode=1, n_features=nf) as pipe:
+        assert pipe.submit_frames([frames[0], None, frames[2], frames[3]])
+        r = pipe.wait()
+        assert list(r["status"]) == [0, binding.SS_ERR_BAD_FRAME, 0, 0] and r["n_keypoints"][1] == 0
+        assert (r["match_idx"][1] == -1).all() and (r["match_idx"][2] == -1).all()
+        n3 = int(r["n_keypoints"][3])
+        m = oracle.match(want[3][1], want[2][1])
+        assert np.array_equal(r["match_idx"][3, :n3], m[0]) and np.array_equal(r["match_d1"][3, :n3], m[1])
+        pipe.release(r["slot"])
+
+
+def test_binding_rejects_frames_smaller_than_the_pipe_shape():
+    with binding.Pipe(0, 640, 480, batch=2, depth=2, match_mode=-1, n_features=300) as pipe:
+        with pytest.raises(ValueError):
+            pipe.submit_frames([np.zeros((480, 639), np.uint8), np.zeros((480, 640), np.uint8)])
+        with pytest.raises(ValueError):
+            pipe.submit_batch_array(np.zeros((2, 479, 640), np.uint8))
+        assert pipe.in_flight() == 0
+
+
+def test_many_short_chunks_repeated_every_record_right(oracle):
+    """2000 queries against 20 000-row slabs = 79 chunks of 8 tiles, 1264 short blocks, five waves per SIMD: the shape in which a
+    fragment read still in flight across the step barrier met the LDS-DMA that refills its slot (one wrong second-best in
+    ~30 runs, found by this round's suite).  Twenty repetitions, every record of every slab against the oracle."""
+    import torch
+    n_parts, nq, n_db = 8, 2000, 160000
+    rng = np.random.default_rng(n_db)
+    q = rng.integers(0, 256, size=(nq, 32), dtype=np.uint8)
+    db = rng.integers(0, 256, size=(n_db, 32), dtype=np.uint8)
+    per = n_db // n_parts
+    dev = torch.device("cuda:0")
+    tq, tdb = torch.from_numpy(q).to(dev), torch.from_numpy(db).to(dev)
+    parts = torch.empty((n_parts, nq), dtype=torch.int64, device=dev)
+    want = [oracle.match(q, db[r * per:(r + 1) * per], th=-1) for r in range(n_parts)]
+    with binding.OrbContext(0) as ctx:
+        for rep in range(20):
+            for r in range(n_parts):
+                ctx.match_partial_device(tq.data_ptr(), nq, tdb[r * per:(r + 1) * per].data_ptr(), per, r * per, parts[r].data_ptr())
+            ctx.synchronize()
+            rec = parts.cpu().numpy().view(np.dtype([("d1", "<u2"), ("d2", "<u2"), ("row", "<i4")]))
+            for r in range(n_parts):
+                assert np.array_equal(rec["row"][r], want[r][0] + r * per) and np.array_equal(rec["d1"][r], want[r][1]) and \
+                    np.array_equal(rec["d2"][r], want[r][2]), (rep, r)

@@ -245,6 +245,31 @@ def test_frontdoor_end_to_end_frames(frontdoor, oracle, extra_env):
     assert want[-1]["state"] == 4  # the unrelated colour frame loses tracking: no pose for it
 
 
+@pytest.mark.gpu
+def test_frontdoor_exits_nonzero_when_the_gpu_pipeline_fails(frontdoor):
+    """read-ahead: a pipe call that fails for a reason other than a bad frame (here: an injected half-way failure of the second
+    batch's submission) must end the process with a non-zero code for a supervised restart -- never spin on busy slots"""
+    w, h = 640, 480
+    frames = [synth.parallax_frame(77, w, h, t) for t in range(6)]
+    host = FakeHost()
+    b = run_backend(host, {"SENDSLAM_READAHEAD": "2", "SENDSLAM_TEST_PIPE_FAIL_BATCH": "1"})
+    try:
+        host.accept()
+        dims = {"width": w, "height": h, "channels": 1}
+        host.send(wire.build_calibration_packet([[500, 0, 320], [0, 500, 240], [0, 0, 1]], [0, 0, 0, 0], dims))
+        blob = b"".join(wire.build_frame_packet(wire.encode_to_ppm(f), dims, camera_id=1, timestamp=1.0 + t / 30) for t, f in enumerate(frames))
+        try:
+            host.send(blob)
+        except OSError:
+            pass  # the backend may be gone before everything is written
+        rc = b.wait(timeout=60)
+    finally:
+        host.close()
+    text = b.logs(200)[1]
+    assert rc == 3, text
+    assert "GPU pipeline failed (ss_pipe_submit): injected failure" in text and "supervised restart" in text
+
+
 def test_docker_cli_shim_drives_the_frontdoor_like_dockerhandler(frontdoor, tmp_path):
     """The four docker invocations of SendSlam.DockerHandler (docker_handler.ex:117-182), answered by
     frontdoor/run_frontdoor.sh: run -d --rm --name ... -e K=V IMAGE / inspect -f ... / logs --tail / rm -f."""
