@@ -32,6 +32,8 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                          ">= 60 % HBM roofline on the Hamming-match kernel"
   host_pipeline          the same step fed from HOST memory through the pinned ring of the C ABI (ss_pipe_*):
                          frames/s and PCIe GB/s, copies overlapped with the kernels.  Never `value`.
+  frontdoor              the literal drop-in: this process plays SlamHandler over TCP + MessagePack + PNM against the front
+                         door binary (read-ahead 16, pacing off): frames/s, and where the front door's time goes
   kernels                per-stage durations
   cpu_baseline           the CPU oracle (a port: the reference's ORB-SLAM3 cannot be built here) timed on
                          this host on a bounded sample of the same frames, 1 thread like the reference shim
@@ -562,6 +564,92 @@ def bench_host_pipeline(binding, frames_sets, w, h, nf, B, local_rank, depth=4, 
                     "pinned slot (PCIe + kernels only)"}
 
 
+def bench_frontdoor(n_frames=192, readahead=16):
+    """The LITERAL drop-in: this process plays SlamHandler (slam_handler.ex:140-156, 275-291: one TCP connection, u32 length +
+    MessagePack map per frame with the PPM/PGM file as a bin), the front door binary connects like the container does
+    (ORB_SLAM3_WS_PORT), receives, decodes the PNM into pinned slots, extracts on the GPU, tracks, answers.  Pacing off,
+    read-ahead 16 (SENDSLAM_NO_PACING=1).  Frames are pre-encoded, so the sender costs one sendall; a "features" message per
+    frame tells when each frame has been answered.  Config 1 of BASELINE.json (640x480 colour P6, 1250 features) and the metric's
+    frame shape (1280x720 gray P5, 2000 features).  Never `value`."""
+    import socket
+    import subprocess
+    import threading
+    import msgpack
+    from send_slam_amd import synth, wire
+    fd_bin = os.path.join(ROOT, "send-slam_amd", "frontdoor", "sendslam_frontdoor")
+    if not os.path.exists(fd_bin):
+        return {"error": "front door binary not built"}
+    out = {}
+    for name, (w, h, ch, nfeat) in {"640x480_P6_1250": (640, 480, 3, 1250), "1280x720_P5_2000": (1280, 720, 1, 2000)}.items():
+        n_distinct = 24
+        sc = synth.scene(4000, w, h)
+        base = [synth.parallax_frame(4000, w, h, t, sc=sc) for t in range(n_distinct)]
+        if ch == 3:
+            base = [np.repeat(f[:, :, None], 3, axis=2) for f in base]
+        order = list(range(n_distinct)) + list(range(n_distinct - 2, 0, -1))  # back and forth: continuous motion
+        dims = {"width": w, "height": h, "channels": ch}
+        enc = [wire.encode_to_ppm(f) for f in base]
+        pk = [wire.build_frame_packet(enc[order[i % len(order)]], dims, camera_id=1, timestamp=1.0 + i / 30.0) for i in range(n_frames)]
+        blob = b"".join(pk)
+        calib = wire.build_calibration_packet([[0.8 * w, 0, w / 2], [0, 0.8 * w, h / 2], [0, 0, 1]], [0, 0, 0, 0], dims)
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("127.0.0.1", 0))
+        srv.listen(1)
+        env = dict(os.environ, ORB_SLAM3_WS_PORT=str(srv.getsockname()[1]), SENDSLAM_NO_PACING="1", SENDSLAM_READAHEAD=str(readahead),
+                   SENDSLAM_EMIT_FEATURES="1", SENDSLAM_TIMING="1", SENDSLAM_ORB_NFEATURES=str(nfeat),
+                   LD_LIBRARY_PATH=os.path.join(ROOT, "send-slam_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        proc = subprocess.Popen([fd_bin], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        try:
+            srv.settimeout(60)
+            conn, _ = srv.accept()
+            conn.settimeout(120)
+            conn.setsockopt(socket.SOL_SOCKET, socket.SO_SNDBUF, 8 << 20)
+            stamps, states = [], []
+
+            def reader():
+                buf = b""
+                while len(stamps) < n_frames:
+                    chunk = conn.recv(1 << 16)
+                    if not chunk:
+                        return
+                    pkts, buf = wire.extract_packets(buf + chunk)
+                    for p_ in pkts:
+                        m = msgpack.unpackb(p_, raw=False)
+                        if m.get("type") == "features":
+                            stamps.append(time.perf_counter())
+                            states.append(m["tracking_state"])
+            conn.sendall(calib)
+            warm = pk[:readahead]  # first batch: pipe creation, kernel load
+            th = threading.Thread(target=reader)
+            th.start()
+            t0 = time.perf_counter()
+            conn.sendall(blob)
+            t_sent = time.perf_counter() - t0
+            th.join(timeout=180)
+            conn.sendall(wire.build_terminate_packet())
+            log = proc.communicate(timeout=60)[0]
+        finally:
+            srv.close()
+            if proc.poll() is None:
+                proc.kill()
+        if len(stamps) < n_frames:
+            out[name] = {"error": f"{len(stamps)} of {n_frames} frames answered", "log_tail": log[-400:] if "log" in dir() else ""}
+            continue
+        # steady state: from the answer of the first read-ahead batch's last frame to the last answer
+        k0 = len(warm)
+        rate = (n_frames - k0) / (stamps[-1] - stamps[k0 - 1])
+        tline = next((ln for ln in log.splitlines() if ln.startswith("timing:")), "")
+        tok = tline.split()
+        tm = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)} if tok else {}
+        biggest = max((k for k in tm if k != "wall"), key=lambda k: tm[k]) if tm else None
+        out[name] = {"frames_per_s": round(rate, 1), "ms_per_frame": round(1e3 / rate, 4), "frames": n_frames, "read_ahead": readahead,
+                     "payload_bytes_per_frame": len(pk[0]), "socket_GBps": round(rate * len(pk[0]) / 1e9, 3),
+                     "sender_sendall_s": round(t_sent, 4), "frames_tracking_ok": int(sum(1 for s_ in states if s_ == 2)),
+                     "frontdoor_seconds": tm, "largest_share": biggest}
+    return out
+
+
 def exchange_legs(timeout_s=240):
     import socket
     import subprocess
@@ -887,13 +975,18 @@ def main():
         c.close()
     del d_sets, outs
 
-    match_stream = host_pipe = None
+    match_stream = host_pipe = frontdoor = None
     if rank == 0 and not a.timed_only:
         torch.cuda.empty_cache()
         match_stream = bench_match_stream(binding, torch, dev, local_rank)
         torch.cuda.empty_cache()
         if world == 1:
             host_pipe = bench_host_pipeline(binding, frames, w, h, nf, B, local_rank)
+            if os.environ.get("SENDSLAM_BENCH_NO_FRONTDOOR") != "1":
+                try:
+                    frontdoor = bench_frontdoor()
+                except Exception as ex:  # the leg must never take the metric line down
+                    frontdoor = {"error": repr(ex)}
 
     if use_dist(world):
         dist.destroy_process_group()
@@ -997,7 +1090,7 @@ def main():
         "rounds": len(times), "timed_region_s": round(sum(times), 4), "value_spread": spread, "sustained": sustained,
         "ranks_reported_by_backend": reported, "single_gpu_exchange": single_gpu_exchange,
         "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline,
-        "match_stream_roofline": match_stream, "host_pipeline": host_pipe, "kernels": kernels, "cpu_baseline": cpu_obj,
+        "match_stream_roofline": match_stream, "host_pipeline": host_pipe, "frontdoor": frontdoor, "kernels": kernels, "cpu_baseline": cpu_obj,
         "parity_checked_vs_oracle": parity,
         "parity_note": "oracle = the committed CPU restatement; parity with the real ORB-SLAM3 binary is unpinned (DESIGN.md section 3)",
         "single_frame_host_to_host_ms": None if single_frame_ms is None else round(single_frame_ms, 3),

@@ -1003,6 +1003,10 @@ int orc_pnp_pose_only(int n, const double *pts3d, const double *obs, const doubl
                                   dR[6] * t[0] + dR[7] * t[1] + dR[8] * t[2] + dt[2]};
             memcpy(R, Rn, sizeof(Rn));
             memcpy(t, tn, sizeof(tn));
+            /* the round ends once a step has moved nothing (same rule as the product's sst_pose_only) */
+            double step = 0;
+            for (int a = 0; a < 6; a++) step = fmax(step, fabs(b[a]));
+            if (step < 1e-10) break;
         }
         n_in = 0;
         for (int i = 0; i < n; i++) {

@@ -349,6 +349,8 @@ def pose_only(cam: Camera, pts3d, obs, inv_sigma2, R, t):
             d = np.linalg.solve(H, b)
             dR, dt = _se3_exp(d)
             R, t = dR @ R, dR @ t + dt
+            if np.max(np.abs(d)) < 1e-10:  # the round ends once a step has moved nothing (same rule as sst_pose_only)
+                break
         X = P @ R.T + t
         z = X[:, 2]
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -633,6 +633,11 @@ int sst_pose_only(int n, const double *pts3d, const double *obs, const double *i
                                   dR[6] * t[0] + dR[7] * t[1] + dR[8] * t[2] + dt[2]};
             memcpy(R, Rn, sizeof(Rn));
             memcpy(t, tn, sizeof(tn));
+            /* a round of up to ten steps ends once a step has moved nothing (g2o's optimize(10) stops on its own
+             * convergence test too): Gauss-Newton is there after three or four, the other six cost 60 % of a frame's pose */
+            double step = 0;
+            for (int a = 0; a < 6; a++) step = std::max(step, std::fabs(b[a]));
+            if (step < SST_POSE_STEP_EPS) break;
         }
         n_in = 0;
         for (int i = 0; i < n; i++) {
@@ -924,6 +929,14 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
     cur.p3d.assign((size_t)3 * n, 0.0);
     out = sst_pose_out();
 
+    /* scale^o and scale^(2 o) per octave: the values std::pow returns, looked up instead of recomputed per point */
+    double s1[64], s2[64];
+    for (int o = 0; o < 64; o++) {
+        s1[o] = std::pow(scale_factor, (double)o);
+        s2[o] = std::pow(scale_factor, 2.0 * o);
+    }
+    auto pw1 = [&](int o) { return o >= 0 && o < 64 ? s1[o] : std::pow(scale_factor, (double)o); };
+    auto pw2 = [&](int o) { return o >= 0 && o < 64 ? s2[o] : std::pow(scale_factor, 2.0 * o); };
     const int want = want_match();
     std::vector<int32_t> m;
     if (want != SST_MATCH_NONE) {
@@ -972,8 +985,8 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
                 if (tri[k]) {
                     o1.push_back(x1[2 * k]); o1.push_back(x1[2 * k + 1]);
                     o2.push_back(x2[2 * k]); o2.push_back(x2[2 * k + 1]);
-                    w1.push_back(1.0 / std::pow(scale_factor, 2.0 * ref.octave[m[qi[k]]]));
-                    w2.push_back(1.0 / std::pow(scale_factor, 2.0 * cur.octave[qi[k]]));
+                    w1.push_back(1.0 / pw2(ref.octave[m[qi[k]]]));
+                    w2.push_back(1.0 / pw2(cur.octave[qi[k]]));
                     for (int a = 0; a < 3; a++) X.push_back(p3d[3 * k + a]);
                     ks.push_back(k);
                 }
@@ -1030,11 +1043,11 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
             const double y = cur.R[3] * Q[0] + cur.R[4] * Q[1] + cur.R[5] * Q[2] + cur.t[1];
             const double z = cur.R[6] * Q[0] + cur.R[7] * Q[1] + cur.R[8] * Q[2] + cur.t[2];
             if (z <= 0) continue;
-            const double r = th * std::pow(scale_factor, (double)cur.octave[i]);
+            const double r = th * pw1(cur.octave[i]);
             if (!(std::fabs(cam.fx * x / z + cam.cx - cur.und[2 * i]) < r && std::fabs(cam.fy * y / z + cam.cy - cur.und[2 * i + 1]) < r)) continue;
             for (int a = 0; a < 3; a++) P.push_back(Q[a]);
             obs.push_back(cur.und[2 * i]); obs.push_back(cur.und[2 * i + 1]);
-            w.push_back(1.0 / std::pow(scale_factor, 2.0 * cur.octave[i]));
+            w.push_back(1.0 / pw2(cur.octave[i]));
             qi.push_back(i);
         }
         if (qi.size() >= 20) break;
@@ -1074,12 +1087,12 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
         } else {
             a_pose = prev_pose_id;
             a_xy[0] = prev.und[2 * j]; a_xy[1] = prev.und[2 * j + 1];
-            a_s2 = std::pow(scale_factor, 2.0 * prev.octave[j]);
+            a_s2 = pw2(prev.octave[j]);
         }
         double X[3];
-        const double s2 = std::pow(scale_factor, 2.0 * cur.octave[i]);
+        const double s2v = pw2(cur.octave[i]);
         const double *aR = &pose_hist[(size_t)12 * a_pose], *at = aR + 9;
-        if (sst_triangulate(cam, a_xy, &cur.und[2 * i], aR, at, cur.R, cur.t, a_s2, s2, X)) {
+        if (sst_triangulate(cam, a_xy, &cur.und[2 * i], aR, at, cur.R, cur.t, a_s2, s2v, X)) {
             cur.has3d[i] = 1;
             for (int a = 0; a < 3; a++) cur.p3d[3 * i + a] = X[a];
         } else {

@@ -90,6 +90,8 @@ struct sst_pose_out {
 };
 
 enum { SST_MATCH_NONE = 0, SST_MATCH_REF = 1, SST_MATCH_PREV = 2 };
+/* sst_pose_only: a Gauss-Newton round ends when no component of the se(3) step exceeds this */
+#define SST_POSE_STEP_EPS 1e-10
 enum { SST_KEEP_NONE = 0, SST_KEEP_AS_REF = 1, SST_KEEP_AS_PREV = 2 };
 
 struct sst_tracker {

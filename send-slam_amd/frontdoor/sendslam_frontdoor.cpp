@@ -27,6 +27,7 @@
  *                              slam_handler.ex:131-132)
  *   SENDSLAM_ORB_NFEATURES=n   override the 1250 literal (BASELINE.json benches use 2000)
  *   SENDSLAM_DEVICE=k          HIP device ordinal (one backend process per GPU / camera)
+ *   SENDSLAM_TIMING=1          print where the connection's wall time went with the shutdown summary (bench.py "frontdoor")
  *   SENDSLAM_NO_PACING=1       no sleep between frames (:618-624 switched off) AND read-ahead: frames already
  *                              queued on the socket are decoded straight into a pinned slot of an ss_pipe (up to
  *                              SENDSLAM_READAHEAD per batch, default 16), extracted as one batch while the next
@@ -395,6 +396,16 @@ int main(int argc, char **argv)
     vector<double> openStamps;
     vector<chrono::steady_clock::time_point> submitTimes; /* per batch in flight, oldest first */
 
+    /* SENDSLAM_TIMING=1: where the wall time of the connection goes, printed with the shutdown summary (seconds):
+     * recv = blocked in recv() for message bytes, parse = MessagePack decode, decode = PNM payload -> pinned slot / frame
+     * buffer, submit = ss_pipe_submit, wait = blocked in ss_pipe_wait (GPU not done yet), track = ss_track_features /
+     * ss_track, send = pose / features packets */
+    const bool timing = env_int("SENDSLAM_TIMING", 0) != 0;
+    double tRecv = 0, tParse = 0, tDecode = 0, tSubmit = 0, tWait = 0, tTrack = 0, tSend = 0;
+    const auto tStart = chrono::steady_clock::now();
+    auto secs_since = [](chrono::steady_clock::time_point t0) {
+        return chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - t0).count();
+    };
     /* A pipe call that fails for a reason other than a bad frame (a HIP error: the GPU or its driver is in trouble) ends
      * the process with a non-zero code, so that the supervisor starts a fresh backend (docker_handler.ex:117-145 stops itself
      * on a dead container for exactly that).  Carrying on would mean polling slots that can never complete. */
@@ -408,7 +419,10 @@ int main(int argc, char **argv)
     auto finish_batch = [&]() -> bool {
         ss_pipe_result r{};
         if (pipeFailed || batchesInFlight <= 0 || submitTimes.empty()) return false;
-        if (ss_pipe_wait(pipe, &r) != SS_OK) {
+        const auto tw = chrono::steady_clock::now();
+        const int wrc = ss_pipe_wait(pipe, &r);
+        tWait += secs_since(tw);
+        if (wrc != SS_OK) {
             pipe_fatal("ss_pipe_wait");
             return false;
         }
@@ -429,7 +443,10 @@ int main(int argc, char **argv)
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl;
                 continue;
             }
+            tTrack += secs_since(t1);
+            const auto ts1 = chrono::steady_clock::now();
             emit_tracked(tracked, r.camera_id[i], r.timestamp[i]);
+            tSend += secs_since(ts1);
             const double ttrack = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - t1).count();
             trackSeconds.push_back((float)(ttrack + extractShare));
         }
@@ -442,7 +459,7 @@ int main(int argc, char **argv)
         static int submissions = 0;
         if (env_int("SENDSLAM_TEST_PIPE_FAIL_BATCH", -1) == submissions++) ss_pipe_debug_inject_failure(pipe, 4);
         if (pipeFailed) {
-        } else if (ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()) != SS_OK) {
+        } else if ([&] { const auto t0 = chrono::steady_clock::now(); const int rc = ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()); tSubmit += secs_since(t0); return rc; }() != SS_OK) {
             pipe_fatal("ss_pipe_submit");
         } else {
             batchesInFlight++;
@@ -473,7 +490,9 @@ int main(int argc, char **argv)
         if (pipe && (openN > 0 || batchesInFlight > 0) && !input_queued()) drain_pipe(); /* idle socket: answer now */
         if (pipeFailed) break;
         uint8_t lengthBuffer[4];
+        const auto tr0 = chrono::steady_clock::now();
         const int r = readExact(lengthBuffer, 4);
+        tRecv += secs_since(tr0);
         if (r <= 0) drain_pipe();
         if (r == 0) {
             cout << "Connection closed by server." << endl;
@@ -497,13 +516,17 @@ int main(int argc, char **argv)
             return 1;
         }
         payload.resize(messageLength);
-        if (readExact(payload.data(), payload.size()) != 1) {
+        const auto tr1 = chrono::steady_clock::now();
+        const int gotPayload = readExact(payload.data(), payload.size());
+        tRecv += secs_since(tr1);
+        if (gotPayload != 1) {
             cerr << "Connection closed before full message was received." << endl;
             break;
         }
 
         MessagePacket packet;
         ssmp::value root;
+        const auto tp0 = chrono::steady_clock::now();
         try {
             root = ssmp::decoder(payload.data(), payload.size()).parse();
             if (!parse_message(root, packet)) {
@@ -515,6 +538,7 @@ int main(int argc, char **argv)
             continue;
         }
 
+        tParse += secs_since(tp0);
         if (packet.type != "frame") drain_pipe(); /* messages are answered in order */
         if (pipeFailed) break;
         if (packet.type == "terminate" || packet.type == "shutdown") {
@@ -614,7 +638,9 @@ int main(int argc, char **argv)
                     if (arc != SS_OK && !pipeFailed) pipe_fatal("ss_pipe_acquire");
                     if (pipeFailed) break;
                 }
+                const auto td0 = chrono::steady_clock::now();
                 pnm_copy(packet.imageData + pnmOff, w, h, ch, openSlot.pixels + (size_t)openN * openSlot.frame_stride, (size_t)openSlot.row_stride);
+                tDecode += secs_since(td0);
                 openCams.push_back(packet.camera_id);
                 openStamps.push_back(packet.timestamp);
                 openN++;
@@ -625,7 +651,9 @@ int main(int argc, char **argv)
             }
 
             pix.resize((size_t)w * h * ch);
+            const auto td0 = chrono::steady_clock::now();
             pnm_copy(packet.imageData + pnmOff, w, h, ch, pix.data(), (size_t)w * ch);
+            tDecode += secs_since(td0);
             const auto t1 = chrono::steady_clock::now();
             /* TrackMonocular :594 -> Twc + tracking state :596 */
             ss_pose tracked{};
@@ -634,7 +662,10 @@ int main(int argc, char **argv)
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl; /* bad frame => log + skip */
                 continue;
             }
+            tTrack += secs_since(t1);
+            const auto ts1 = chrono::steady_clock::now();
             emit_tracked(tracked, packet.camera_id, packet.timestamp);
+            tSend += secs_since(ts1);
             const auto t2 = chrono::steady_clock::now();
             const double ttrack = chrono::duration_cast<chrono::duration<double>>(t2 - t1).count();
             trackSeconds.push_back((float)ttrack);
@@ -662,6 +693,9 @@ int main(int argc, char **argv)
             cout << "Frames processed: " << trackSeconds.size() << endl;
             cout << "median tracking time: " << trackSeconds[trackSeconds.size() / 2] << endl;
             cout << "mean tracking time: " << totaltime / trackSeconds.size() << endl;
+            if (timing)
+                cout << "timing: wall " << secs_since(tStart) << " recv " << tRecv << " parse " << tParse << " decode " << tDecode << " submit " << tSubmit
+                     << " wait " << tWait << " track " << tTrack << " send " << tSend << endl;
         } else {
             cout << "No frames processed." << endl;
         }
