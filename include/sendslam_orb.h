@@ -284,6 +284,13 @@ int ss_xchg_status(ss_xchg *x);
 int ss_xchg_allgather(ss_xchg *x, ss_ctx *ctx, const void *const *d_segments, const int64_t *segment_bytes, int n_segments,
                       const void **d_gathered, int64_t *rank_stride);
 int ss_xchg_broadcast(ss_xchg *x, ss_ctx *ctx, int root, void *d_buf, int64_t bytes);
+/* Config 4 in one call, for hosts that hold no device memory of their own (the TCP front door with SENDSLAM_SHARD=r/2, the NIF):
+ * all-gathers the descriptor block and keypoint count of the frame ctx extracted last (ss_extract / ss_track; frame 0 of a
+ * batch) with the peer rank's, matches this eye's descriptors against the peer eye's (th, ratio as in ss_match) and copies
+ * idx / d1 / d2 (kp_capacity entries each; any of them may be NULL) to the host.  Both ranks call it once per stereo pair, in
+ * lockstep.  *n_own / *n_peer: the two keypoint counts.  Synchronous. */
+int ss_stereo_exchange_match(ss_ctx *ctx, ss_xchg *x, int peer_rank, int th, int ratio_num, int ratio_den, int32_t *idx,
+                             uint16_t *d1, uint16_t *d2, int32_t *n_own, int32_t *n_peer);
 
 int ss_synchronize(ss_ctx *ctx);
 /* Orders the context's stream after everything enqueued so far on another stream of the same device

@@ -975,6 +975,42 @@ int ss_match_fold_strided_device(ss_ctx *c, const void *d_parts, int n_parts, in
     return SS_OK;
 }
 
+int ss_stereo_exchange_match(ss_ctx *c, ss_xchg *x, int peer_rank, int th, int ratio_num, int ratio_den, int32_t *idx, uint16_t *d1,
+                             uint16_t *d2, int32_t *n_own, int32_t *n_peer)
+{
+    if (!c || !x) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->have_geom || c->last_n_frames <= 0) return fail(c, SS_ERR_STATE, "ss_stereo_exchange_match: no frame has been extracted");
+    if (peer_rank < 0) return fail(c, SS_ERR_INVALID_ARG, "ss_stereo_exchange_match: bad peer rank");
+    const int kcap = c->hg.kcap;
+    const int64_t blk = (int64_t)kcap * SS_DESC_BYTES;
+    const void *segs[2] = {c->desc, c->n_kp};
+    const int64_t sizes[2] = {blk, (int64_t)sizeof(int32_t)};
+    const void *gathered = nullptr;
+    int64_t stride = 0;
+    int rc = ss_xchg_allgather(x, c, segs, sizes, 2, &gathered, &stride);
+    if (rc != SS_OK) return fail(c, rc, std::string("ss_stereo_exchange_match: ") + ss_xchg_last_error(x));
+    rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)kcap * 8);
+    if (rc != SS_OK) return rc;
+    const uint8_t *peer = (const uint8_t *)gathered + (int64_t)peer_rank * stride;
+    int32_t *di = (int32_t *)c->d_mout;
+    uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)kcap * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)kcap * 6);
+    rc = ss_match_pairs_device(c, c->desc, c->n_kp, peer, peer + blk, 1, kcap, th, ratio_num, ratio_den, di, dd1, dd2);
+    if (rc != SS_OK) return rc;
+    int32_t counts[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&counts[0], c->n_kp, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&counts[1], peer + blk, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (idx) HIP_TRY(c, hipMemcpyAsync(idx, di, (size_t)kcap * 4, hipMemcpyDeviceToHost, c->stream));
+    if (d1) HIP_TRY(c, hipMemcpyAsync(d1, dd1, (size_t)kcap * 2, hipMemcpyDeviceToHost, c->stream));
+    if (d2) HIP_TRY(c, hipMemcpyAsync(d2, dd2, (size_t)kcap * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = ss_xchg_status(x);
+    if (rc != SS_OK) return fail(c, rc, std::string("ss_stereo_exchange_match: ") + ss_xchg_last_error(x));
+    if (n_own) *n_own = counts[0];
+    if (n_peer) *n_peer = counts[1];
+    return SS_OK;
+}
+
 int ss_wait_stream(ss_ctx *c, void *hip_stream)
 {
     if (!c) return SS_ERR_INVALID_ARG;

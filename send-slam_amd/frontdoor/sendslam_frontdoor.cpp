@@ -27,6 +27,11 @@
  *                              slam_handler.ex:131-132)
  *   SENDSLAM_ORB_NFEATURES=n   override the 1250 literal (BASELINE.json benches use 2000)
  *   SENDSLAM_DEVICE=k          HIP device ordinal (one backend process per GPU / camera)
+ *   SENDSLAM_SHARD=r/2         stereo (BASELINE.json config 4): this process is eye r of a pair of front doors, one per camera / GPU
+ *                              (SENDSLAM_DEVICE); after every tracked frame the two exchange their descriptor blocks through
+ *                              ss_xchg_* (peer-mapped device memory, rendezvous at SENDSLAM_XCHG_PATH) and each matches its eye
+ *                              against the other's: the count goes into the "features" message (stereo_matches) and the log.
+ *                              Both eyes must receive frame k before either can answer it (lockstep cameras); frame by frame only
  *   SENDSLAM_TIMING=1          print where the connection's wall time went with the shutdown summary (bench.py "frontdoor")
  *   SENDSLAM_NO_PACING=1       no sleep between frames (:618-624 switched off) AND read-ahead: frames already
  *                              queued on the socket are decoded straight into a pinned slot of an ss_pipe (up to
@@ -321,6 +326,15 @@ int main(int argc, char **argv)
     params.n_features = env_int("SENDSLAM_ORB_NFEATURES", params.n_features);
     const int device = env_int("SENDSLAM_DEVICE", 0);
     const bool emitFeatures = env_int("SENDSLAM_EMIT_FEATURES", 0) != 0;
+    int shardRank = -1, shardWorld = 0;
+    if (const char *sh = getenv("SENDSLAM_SHARD")) {
+        if (sscanf(sh, "%d/%d", &shardRank, &shardWorld) != 2 || shardWorld != 2 || shardRank < 0 || shardRank >= shardWorld) {
+            cerr << "SENDSLAM_SHARD must be r/2 (stereo: eye r of two); ignoring '" << sh << "'" << endl;
+            shardRank = -1;
+        }
+    }
+    ss_xchg *xchg = nullptr;
+    int stereoMatches = -1;
 
     ss_ctx *ctx = nullptr;
     vector<float> trackSeconds;
@@ -371,7 +385,8 @@ int main(int argc, char **argv)
         }
         if (emitFeatures) {
             ssmp::packer pk;
-            pk.pack_map(8);
+            pk.pack_map(stereoMatches >= 0 ? 9 : 8);
+            if (stereoMatches >= 0) { pk.pack("stereo_matches"); pk.pack(stereoMatches); }
             pk.pack("type");           pk.pack("features");
             pk.pack("timestamp");      pk.pack(timestamp);
             pk.pack("camera_id");      pk.pack(camera_id);
@@ -386,7 +401,7 @@ int main(int argc, char **argv)
 
     /* Read-ahead (SENDSLAM_NO_PACING=1): queued frames go through an ss_pipe in batches; poses come out in frame order. */
     const bool noPacing = env_int("SENDSLAM_NO_PACING", 0) != 0;
-    const int readAhead = noPacing ? max(1, min(64, env_int("SENDSLAM_READAHEAD", 16))) : 1;
+    const int readAhead = noPacing && shardRank < 0 ? max(1, min(64, env_int("SENDSLAM_READAHEAD", 16))) : 1;
     ss_pipe *pipe = nullptr;
     ss_camera pipeCam{};
     int pipeW = 0, pipeH = 0, pipeCh = 0;
@@ -662,6 +677,32 @@ int main(int argc, char **argv)
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl; /* bad frame => log + skip */
                 continue;
             }
+            if (shardRank >= 0) {
+                /* config 4: exchange this frame's descriptors with the other eye's front door, match across the eyes */
+                if (!xchg) {
+                    const char *xp = getenv("SENDSLAM_XCHG_PATH");
+                    if (ss_xchg_create(device, shardRank, shardWorld, 4 << 20, xp ? xp : "/tmp/sendslam_stereo.sock", env_int("SENDSLAM_XCHG_TIMEOUT_MS", 20000), &xchg) != SS_OK) {
+                        cerr << "Stereo exchange unavailable: " << ss_xchg_last_error(nullptr) << endl;
+                        shardRank = -1;
+                    }
+                }
+                stereoMatches = -1;
+                if (xchg) {
+                    static vector<int32_t> sidx(65536); /* >= kp_capacity of any geometry (<= 16 levels x 2048 per level) */
+                    int32_t nOwn = 0, nPeer = 0;
+                    const int src = ss_stereo_exchange_match(ctx, xchg, 1 - shardRank, 50, 9, 10, sidx.data(), nullptr, nullptr, &nOwn, &nPeer);
+                    if (src != SS_OK) {
+                        cerr << "Stereo exchange failed: " << ss_last_error(ctx) << endl;
+                        ss_xchg_destroy(xchg);
+                        xchg = nullptr;
+                        shardRank = -1;
+                    } else {
+                        stereoMatches = 0;
+                        for (int i = 0; i < nOwn && i < (int)sidx.size(); i++) stereoMatches += sidx[(size_t)i] >= 0;
+                        cout << "stereo: " << stereoMatches << " of " << nOwn << " keypoints matched in the other eye (" << nPeer << " there)" << endl;
+                    }
+                }
+            }
             tTrack += secs_since(t1);
             const auto ts1 = chrono::steady_clock::now();
             emit_tracked(tracked, packet.camera_id, packet.timestamp);
@@ -682,6 +723,7 @@ int main(int argc, char **argv)
     }
 
     destroy_pipe();
+    if (xchg) ss_xchg_destroy(xchg);
     ::shutdown(fd, SHUT_RDWR);
     ::close(fd);
 

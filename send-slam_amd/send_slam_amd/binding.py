@@ -32,7 +32,7 @@ EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy",
            "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
            "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight",
            "ss_match_fold_strided_device", "ss_xchg_create", "ss_xchg_destroy", "ss_xchg_last_error", "ss_xchg_status",
-           "ss_xchg_allgather", "ss_xchg_broadcast", "ss_pipe_debug_inject_failure"]
+           "ss_xchg_allgather", "ss_xchg_broadcast", "ss_pipe_debug_inject_failure", "ss_stereo_exchange_match"]
 
 
 class OrbParams(C.Structure):
@@ -173,6 +173,8 @@ def load():
     lib.ss_xchg_allgather.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int,
                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.ss_xchg_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.ss_stereo_exchange_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.ss_pipe_create.argtypes = [C.c_int, C.POINTER(OrbParams), C.POINTER(Camera), C.POINTER(PipeConfig),
                                    C.POINTER(C.c_void_p)]
     lib.ss_pipe_destroy.argtypes = [C.c_void_p]
@@ -433,6 +435,20 @@ class Exchange:
         base, stride = C.c_void_p(), C.c_int64()
         self._check(self._lib.ss_xchg_allgather(self._h, ctx._h, ptrs, sizes, n, C.byref(base), C.byref(stride)))
         return base.value, stride.value
+
+    def stereo_match(self, ctx: "OrbContext", peer: int, kp_capacity: int, th: int = 50, ratio_num: int = 9, ratio_den: int = 10):
+        """ss_stereo_exchange_match: the frame ctx extracted last against the peer rank's -> (idx, d1, d2 over this eye's
+        keypoints, peer's keypoint count)"""
+        idx = np.empty(kp_capacity, np.int32)
+        d1 = np.empty(kp_capacity, np.uint16)
+        d2 = np.empty(kp_capacity, np.uint16)
+        n_own, n_peer = C.c_int32(), C.c_int32()
+        rc = self._lib.ss_stereo_exchange_match(ctx._h, self._h, int(peer), th, ratio_num, ratio_den, idx.ctypes.data, d1.ctypes.data,
+                                                d2.ctypes.data, C.byref(n_own), C.byref(n_peer))
+        if rc < 0:
+            raise OrbError(rc, (self._lib.ss_last_error(ctx._h) or b"").decode())
+        n = n_own.value
+        return idx[:n], d1[:n], d2[:n], n_peer.value
 
     def broadcast(self, ctx: "OrbContext", root: int, d_buf: int, nbytes: int):
         self._check(self._lib.ss_xchg_broadcast(self._h, ctx._h, int(root), C.c_void_p(d_buf), int(nbytes)))

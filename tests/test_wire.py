@@ -300,3 +300,43 @@ def test_docker_cli_shim_drives_the_frontdoor_like_dockerhandler(frontdoor, tmp_
     finally:
         subprocess.run([sh, "rm", "-f", "net-orbslam"], capture_output=True, env=env)
         host.close()
+
+
+@pytest.mark.gpu
+def test_two_front_doors_as_a_stereo_pair_exchange_and_match(frontdoor, tmp_path):
+    """BASELINE.json config 4 from the hosts the reference has: two front door processes (SENDSLAM_SHARD=0/2 and 1/2, here both on
+    GPU 0), one fake SlamHandler each.  The right eye sees the left eye's frames 24 px further left; after every frame the two
+    processes exchange descriptor blocks through ss_xchg_* and match across the eyes: the features message carries the count."""
+    w, h = 640, 480
+    sc = synth.scene(4242, w + 64, h)
+    m = synth._MARGIN
+    eyes = [[np.clip(sc[m + 2 * t:m + 2 * t + h, m + 24 * e + 3 * t:m + 24 * e + 3 * t + w], 0, 255).astype(np.uint8) for t in range(4)] for e in range(2)]
+    hosts = [FakeHost(), FakeHost()]
+    xp = str(tmp_path / "stereo.sock")
+    backs = [run_backend(hosts[e], {"SENDSLAM_SHARD": f"{e}/2", "SENDSLAM_XCHG_PATH": xp, "SENDSLAM_EMIT_FEATURES": "1"}) for e in range(2)]
+    try:
+        dims = {"width": w, "height": h, "channels": 1}
+        for e in range(2):
+            hosts[e].accept()
+            hosts[e].send(wire.build_calibration_packet([[500, 0, 320], [0, 500, 240], [0, 0, 1]], [0, 0, 0, 0], dims, camera_id=e + 1))
+        for t in range(4):  # lockstep cameras
+            for e in range(2):
+                hosts[e].send(wire.build_frame_packet(wire.encode_to_ppm(eyes[e][t]), dims, camera_id=e + 1, timestamp=1.0 + t / 30))
+        msgs = []
+        for e in range(2):  # a pose packet comes only while tracking is OK: read until four "features" messages are in
+            while sum(x.get("type") == "features" for x in hosts[e].inbound) < 4:
+                hosts[e].recv_packets(len(hosts[e].inbound) + 1)
+            msgs.append([x for x in hosts[e].inbound if x.get("type") == "features"][:4])
+        for e in range(2):
+            hosts[e].send(wire.build_terminate_packet())
+        rcs = [b.wait(timeout=60) for b in backs]
+    finally:
+        for hst in hosts:
+            hst.close()
+    for e in range(2):
+        text = backs[e].logs(200)[1]
+        assert rcs[e] == 0, text
+        assert len(msgs[e]) == 4, text
+        for x in msgs[e]:
+            assert x["stereo_matches"] > 0.5 * x["n_keypoints"] > 100, (e, x, text)
+        assert "keypoints matched in the other eye" in text
