@@ -15,6 +15,9 @@ defmodule SendSlam.HipNif do
   def pipe_open(_device, _n_features, _w, _h, _channels, _batch, _depth, _match_mode, _rgb), do: :erlang.nif_error(:nif_not_loaded)
   def pipe_submit(_pipe, _frames, _camera_id, _first_timestamp, _dt), do: :erlang.nif_error(:nif_not_loaded)
   def pipe_wait(_pipe), do: :erlang.nif_error(:nif_not_loaded)
+  # config 4: one HipBackend per eye; both call xchg_open with the same rendezvous path, then stereo_match once per stereo pair
+  def xchg_open(_device, _rank, _world, _max_bytes, _rendezvous, _timeout_ms), do: :erlang.nif_error(:nif_not_loaded)
+  def stereo_match(_ref, _xchg, _peer_rank), do: :erlang.nif_error(:nif_not_loaded)
 end
 
 defmodule SendSlam.HipBackend do

@@ -254,12 +254,69 @@ static ERL_NIF_TERM nif_pipe_wait(ErlNifEnv *env, int argc, const ERL_NIF_TERM a
     return enif_make_tuple2(env, enif_make_atom(env, "ok"), list);
 }
 
+/* ---- config 4 from Elixir: one HipBackend GenServer per eye / GPU, the two exchange descriptor blocks through ss_xchg_*
+ * (peer-mapped device memory, no BEAM message carries a descriptor).  xchg_open is collective: both GenServers call it
+ * with the same rendezvous path; stereo_match once per stereo pair, after track / extract of the pair's frame. ---- */
+static ErlNifResourceType *XCHG_TYPE;
+typedef struct { ss_xchg *x; int rank; } xchg_res;
+
+static void xchg_dtor(ErlNifEnv *env, void *obj)
+{
+    (void)env;
+    xchg_res *r = (xchg_res *)obj;
+    if (r->x) ss_xchg_destroy(r->x);
+    r->x = NULL;
+}
+
+/* xchg_open(device, rank, world, max_bytes, rendezvous :: binary, timeout_ms) -> {:ok, xchg} | error */
+static ERL_NIF_TERM nif_xchg_open(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    int device, rank, world, max_bytes, timeout_ms;
+    ErlNifBinary path;
+    char buf[108];
+    (void)argc;
+    if (!enif_get_int(env, argv[0], &device) || !enif_get_int(env, argv[1], &rank) || !enif_get_int(env, argv[2], &world) ||
+        !enif_get_int(env, argv[3], &max_bytes) || !enif_inspect_binary(env, argv[4], &path) || !enif_get_int(env, argv[5], &timeout_ms) ||
+        path.size >= sizeof(buf))
+        return enif_make_badarg(env);
+    memcpy(buf, path.data, path.size);
+    buf[path.size] = 0;
+    ss_xchg *x = NULL;
+    int rc = ss_xchg_create(device, rank, world, max_bytes, buf, timeout_ms, &x);
+    if (rc != SS_OK) return mk_error(env, rc, ss_xchg_last_error(NULL));
+    xchg_res *r = enif_alloc_resource(XCHG_TYPE, sizeof(xchg_res));
+    r->x = x; r->rank = rank;
+    ERL_NIF_TERM t = enif_make_resource(env, r);
+    enif_release_resource(r);
+    return enif_make_tuple2(env, enif_make_atom(env, "ok"), t);
+}
+
+/* stereo_match(ref, xchg, peer_rank) -> {:ok, n_own, n_peer, match_idx :: binary (n_own x int32, -1 = no match)} | error */
+static ERL_NIF_TERM nif_stereo_match(ErlNifEnv *env, int argc, const ERL_NIF_TERM argv[])
+{
+    ctx_res *c;
+    xchg_res *x;
+    int peer;
+    (void)argc;
+    if (!enif_get_resource(env, argv[0], CTX_TYPE, (void **)&c) || !enif_get_resource(env, argv[1], XCHG_TYPE, (void **)&x) ||
+        !enif_get_int(env, argv[2], &peer))
+        return enif_make_badarg(env);
+    static int32_t idx[65536]; /* >= kp_capacity of any geometry; dirty NIFs of one GenServer do not overlap */
+    int32_t n_own = 0, n_peer = 0;
+    int rc = ss_stereo_exchange_match(c->ctx, x->x, peer, 50, 9, 10, idx, NULL, NULL, &n_own, &n_peer);
+    if (rc != SS_OK) return mk_error(env, rc, ss_last_error(c->ctx));
+    ERL_NIF_TERM mb;
+    memcpy(enif_make_new_binary(env, (size_t)n_own * 4, &mb), idx, (size_t)n_own * 4);
+    return enif_make_tuple4(env, enif_make_atom(env, "ok"), enif_make_int(env, n_own), enif_make_int(env, n_peer), mb);
+}
+
 static int on_load(ErlNifEnv *env, void **priv, ERL_NIF_TERM info)
 {
     (void)priv; (void)info;
     CTX_TYPE = enif_open_resource_type(env, NULL, "sendslam_ctx", ctx_dtor, ERL_NIF_RT_CREATE, NULL);
     PIPE_TYPE = enif_open_resource_type(env, NULL, "sendslam_pipe", pipe_dtor, ERL_NIF_RT_CREATE, NULL);
-    return CTX_TYPE && PIPE_TYPE ? 0 : 1;
+    XCHG_TYPE = enif_open_resource_type(env, NULL, "sendslam_xchg", xchg_dtor, ERL_NIF_RT_CREATE, NULL);
+    return CTX_TYPE && PIPE_TYPE && XCHG_TYPE ? 0 : 1;
 }
 
 static ErlNifFunc funcs[] = {
@@ -272,6 +329,8 @@ static ErlNifFunc funcs[] = {
     {"pipe_open", 9, nif_pipe_open, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"pipe_submit", 5, nif_pipe_submit, ERL_NIF_DIRTY_JOB_CPU_BOUND},
     {"pipe_wait", 1, nif_pipe_wait, ERL_NIF_DIRTY_JOB_IO_BOUND}, /* blocks on the GPU, burns no CPU */
+    {"xchg_open", 6, nif_xchg_open, ERL_NIF_DIRTY_JOB_IO_BOUND},
+    {"stereo_match", 3, nif_stereo_match, ERL_NIF_DIRTY_JOB_IO_BOUND},
 };
 
 ERL_NIF_INIT(Elixir.SendSlam.HipNif, funcs, on_load, NULL, NULL, NULL)
