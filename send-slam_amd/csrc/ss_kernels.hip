@@ -1858,6 +1858,9 @@ __device__ __forceinline__ uint32_t fp4_of_4bits(uint32_t nib)
 #ifndef OD_KP
 #define OD_KP 1 /* measured in the four-context pipeline: 1 -> 93.5-95.4 k frames/s, 2 -> 92.5 k (twice the LDS per block) */
 #endif
+#ifndef OD_PITCH
+#define OD_PITCH 80
+#endif
 template <bool STEER_FMA, int KP>
 __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restrict__ g, const uint8_t *__restrict__ pyr,
                                                          const uint8_t *__restrict__ blur,
@@ -1886,7 +1889,9 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
      * was the busiest unit of this kernel with dword loads (TA_BUSY 75 %); a row of the patch is 3 pieces from the
      * 16-byte boundary at or below kx - 15, a row of the window 4 pieces from the one at or below kx - 18 */
     __shared__ __attribute__((aligned(16))) uint32_t patch_all[4][KP][31 * 12 + 4]; /* + 4: the last row's masked-off tail read */
-    __shared__ __attribute__((aligned(16))) uint32_t win_all[4][KP][37 * 16];
+    /* window rows at an OD_PITCH-byte pitch (>= 64, multiple of 16): at 64 bytes rows r and r + 2 share their banks; at 80 only
+     * rows r and r + 8 do, and the byte gathers of the 64 lanes (anywhere in the window) collide less */
+    __shared__ __attribute__((aligned(16))) uint32_t win_all[4][KP][37 * (OD_PITCH / 4)];
     int slot[KP], level[KP], kx[KP], ky[KP], resp[KP], pitch[KP], px0[KP], wx0[KP];
     size_t fb[KP];
     uint2 ref[KP];
@@ -1941,7 +1946,7 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             if (lane + WAVE * it < 31 * 3) pl[lane + WAVE * it] = pv[k][it];
 #pragma unroll
         for (int it = 0; it < 3; it++)
-            if (lane + WAVE * it < 37 * 4) wl[lane + WAVE * it] = wv[k][it];
+            if (lane + WAVE * it < 37 * 4) wl[((lane + WAVE * it) >> 2) * (OD_PITCH / 16) + ((lane + WAVE * it) & 3)] = wv[k][it];
     }
     wave_sync();
     int m10[KP], m01[KP];
@@ -1995,14 +2000,14 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     /* cvRound without v_rndne + v_cvt: x + (2^23 + 32) has ulp 1, so the sum is the integer nearest to x (ties to even,
      * like cvRound) and its bits are 0x4B000020 + round(x) for |x| <= 32.  The low 24 bits, 32 + round(x), are what the
      * 24-bit multiplier reads; the biases move into one wave-uniform constant: byte index in the staged window =
-     * (18 + row) * 64 + (kx - wx0) + col */
+     * (18 + row) * OD_PITCH + (kx - wx0) + col */
     constexpr float RN_MAGIC = 8388640.f;
     constexpr int RN_BIAS = 0x4B000020;
     uint32_t off0[KP][4], off1[KP][4];
 #pragma unroll
     for (int k = 0; k < KP; k++) {
         const float b = sb_[k], a = ca_[k];
-        const uint32_t kbias = (uint32_t)((18 - 32) * 64 + (kx[k] - wx0[k])) - (uint32_t)RN_BIAS;
+        const uint32_t kbias = (uint32_t)((18 - 32) * OD_PITCH + (kx[k] - wx0[k])) - (uint32_t)RN_BIAS;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t pt = pat[q]; /* x0 y0 x1 y1 as int8 */
@@ -2016,8 +2021,8 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             const int c0 = __float_as_int(__fadd_rn(fc0, RN_MAGIC));
             const int r1 = __float_as_int(__fadd_rn(fr1, RN_MAGIC));
             const int c1 = __float_as_int(__fadd_rn(fc1, RN_MAGIC));
-            off0[k][q] = (uint32_t)(__mul24(r0, 64) + c0) + kbias;
-            off1[k][q] = (uint32_t)(__mul24(r1, 64) + c1) + kbias;
+            off0[k][q] = (uint32_t)(__mul24(r0, OD_PITCH) + c0) + kbias;
+            off1[k][q] = (uint32_t)(__mul24(r1, OD_PITCH) + c1) + kbias;
         }
     }
     int t0[KP][4], t1[KP][4];
