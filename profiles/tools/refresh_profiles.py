@@ -11,8 +11,8 @@ import shutil
 import sys
 
 out_dir = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 shape = "1280x720_n2000"
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE = {"k_ingest_gray16": "ingest", "k_ingest": "ingest", "k_resize_lds": "resize", "k_fast_score": "fast_blur_nms",
@@ -69,6 +69,8 @@ if sq:
 pf_path = os.path.join(here, "per_frame_counters.json")
 pf = json.load(open(pf_path)) if os.path.exists(pf_path) else {}
 ent = pf.setdefault(shape, {})
+for stale in ("k_match_mfma", "k_match_merge"):  # kernels the metric path no longer launches
+    ent.pop(stale, None)
 for n in set(list(traffic) + list(sq)):
     if n == "k_match_stream":
         continue
@@ -95,8 +97,9 @@ for src, dst in ((f"{tag}_prof4", f"{tag}_bench_kernel_stats.csv"), (f"{tag}_pro
     f = newest(src, "*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(here, dst))
-for src, dst in ((f"{tag}_bench_final.json", f"{tag}_bench.json"), (f"{tag}_pcie.json", f"{tag}_pcie.json"),
-                 (f"{tag}_mfma_probe.txt", f"{tag}_mfma_probe.txt"), (f"{tag}_fp4_probe.txt", f"{tag}_fp4_probe.txt"), (f"{tag}_loop_closure.json", f"{tag}_loop_closure.json")):
+for src, dst in ((f"{tag}_bench_final.json", f"{tag}_bench.json"), (f"{tag}_bench_steps20.json", f"{tag}_bench_steps20.json"), (f"{tag}_pcie.json", f"{tag}_pcie.json"),
+                 (f"{tag}_mfma_probe.txt", f"{tag}_mfma_probe.txt"), (f"{tag}_fp4_probe.txt", f"{tag}_fp4_probe.txt"), (f"{tag}_loop_closure.json", f"{tag}_loop_closure.json"),
+                 (f"{tag}_fp4_rate_probe.txt", f"{tag}_fp4_rate_probe.txt"), (f"{tag}_fp4_shape_probe.txt", f"{tag}_fp4_shape_probe.txt")):
     if os.path.exists(os.path.join(out_dir, src)):
         shutil.copy(os.path.join(out_dir, src), os.path.join(here, dst))
 tot = sum(v.get("SQ_INSTS_VALU", 0) for v in sq.values())
