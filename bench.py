@@ -345,7 +345,7 @@ def make_exchange(a, binding, rank, world, local_rank, max_bytes):
     if a.exchange != "native":
         return None
     path = os.environ.get("SENDSLAM_XCHG_PATH") or f"/tmp/sendslam_xchg_{os.environ.get('MASTER_PORT', '29533')}_{a.workload}"
-    return binding.Exchange(local_rank, rank, world, max_bytes, path)
+    return binding.Exchange(local_rank, rank, world, max_bytes, path, timeout_ms=180000)  # ranks reach this point seconds apart
 
 
 def bench_stereo(a):

@@ -270,7 +270,8 @@ int ss_match_fold_strided_device(ss_ctx *ctx, const void *d_parts, int n_parts, 
  * padded to 16 bytes); on return *d_gathered points at [world][*rank_stride] bytes of LOCAL device memory, rank r's
  * block at r * *rank_stride, valid until the second-next message of this exchange.  ss_xchg_broadcast: d_buf of `root` ->
  * d_buf of everybody (in place, like ncclBroadcast).  Both are asynchronous on ctx's stream: enqueue the consumers on the same
- * stream.  Every rank must issue the same sequence of messages.  A peer that does not show up within the time limit ends
+ * stream.  Every rank must issue the same sequence of messages.  timeout_ms bounds the rendezvous of ss_xchg_create (0 = 10 s);
+ * a message waits at most min(timeout_ms, 10 s).  A peer that does not show up within that limit ends
  * the waiting kernel (it never hangs the GPU) and poisons the exchange: ss_xchg_status / the next call return SS_ERR_STATE.
  * ss_xchg_destroy is collective too (a last flag-only message, so that nobody unmaps memory a peer still writes).
  * The reference has nothing here: one camera, one TCP link (orbslam3_mono_networked.cc:387-388, application.ex:80). */

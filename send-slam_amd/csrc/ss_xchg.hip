@@ -44,6 +44,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -312,7 +313,11 @@ int ss_xchg_create(int device_ordinal, int rank, int world, int64_t max_bytes, c
     x->slot = (max_bytes + 255) & ~(int64_t)255;
     x->data_off = ((int64_t)world * XC_FLAG_WORDS * 8 + 255) & ~(int64_t)255;
     x->slab_bytes = x->data_off + 2 * (int64_t)world * x->slot;
-    x->timeout_ticks = (uint64_t)timeout_ms * 100000ull;
+    /* timeout_ms bounds the rendezvous (ranks may reach it far apart: first imports, database setup); a message's wait is
+     * bounded by min(timeout_ms, 10 s) -- a spinning kernel should not outlive a watchdog -- or by SENDSLAM_XCHG_WAIT_MS */
+    int wait_ms = timeout_ms < 10000 ? timeout_ms : 10000;
+    if (const char *e = getenv("SENDSLAM_XCHG_WAIT_MS")) wait_ms = atoi(e) > 0 ? atoi(e) : wait_ms;
+    x->timeout_ticks = (uint64_t)wait_ms * 100000ull;
     x->peer_slab.assign((size_t)world, nullptr);
 #define XC_CREATE_TRY(call)                                                                                   \
     do {                                                                                                      \
