@@ -597,7 +597,7 @@ def bench_frontdoor(n_frames=192, readahead=16):
         srv.bind(("127.0.0.1", 0))
         srv.listen(1)
         env = dict(os.environ, ORB_SLAM3_WS_PORT=str(srv.getsockname()[1]), SENDSLAM_NO_PACING="1", SENDSLAM_READAHEAD=str(readahead),
-                   SENDSLAM_EMIT_FEATURES="1", SENDSLAM_TIMING="1", SENDSLAM_ORB_NFEATURES=str(nfeat),
+                   SENDSLAM_EMIT_FEATURES="1", SENDSLAM_TIMING="1", SENDSLAM_TRACK_TIMING="1", SENDSLAM_ORB_NFEATURES=str(nfeat),
                    LD_LIBRARY_PATH=os.path.join(ROOT, "send-slam_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
         proc = subprocess.Popen([fd_bin], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         try:
@@ -639,14 +639,21 @@ def bench_frontdoor(n_frames=192, readahead=16):
         # steady state: from the answer of the first read-ahead batch's last frame to the last answer
         k0 = len(warm)
         rate = (n_frames - k0) / (stamps[-1] - stamps[k0 - 1])
+        # windows of `readahead` consecutive frames that were all tracked (state OK): what a connection sustains between the
+        # (far more expensive) initialisation attempts; this short synthetic sequence loses track once per 46 frames
+        win = sorted(readahead / (stamps[i] - stamps[i - readahead]) for i in range(max(k0, readahead), n_frames)
+                     if all(s_ == 2 for s_ in states[i - readahead + 1:i + 1]) and stamps[i] > stamps[i - readahead])
         tline = next((ln for ln in log.splitlines() if ln.startswith("timing:")), "")
         tok = tline.split()
         tm = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)} if tok else {}
         biggest = max((k for k in tm if k != "wall"), key=lambda k: tm[k]) if tm else None
+        split = next((ln for ln in log.splitlines() if ln.startswith("ss_track timing")), None)  # SENDSLAM_TRACK_TIMING=1
         out[name] = {"frames_per_s": round(rate, 1), "ms_per_frame": round(1e3 / rate, 4), "frames": n_frames, "read_ahead": readahead,
                      "payload_bytes_per_frame": len(pk[0]), "socket_GBps": round(rate * len(pk[0]) / 1e9, 3),
                      "sender_sendall_s": round(t_sent, 4), "frames_tracking_ok": int(sum(1 for s_ in states if s_ == 2)),
-                     "frontdoor_seconds": tm, "largest_share": biggest}
+                     "frames_per_s_while_tracking": None if not win else round(win[len(win) // 2], 1),
+                     "tracking_states": "".join(str(s_) for s_ in states),
+                     "frontdoor_seconds": tm, "largest_share": biggest, "pose_step_split": split}
     return out
 
 

@@ -29,7 +29,7 @@ int main(int argc, char **argv)
     double total = 0;
     int ok = 0;
     for (int f = 0; f < frames; f++) {
-        const double tx = 0.05 * f;
+        const double tx = 0.02 * f;
         for (int i = 0; i < n; i++) {
             const double x = X[3 * i] - tx, y = X[3 * i + 1], z = X[3 * i + 2];
             xy[2 * i] = (float)(1000 * x / z + 640 + noise(rng));

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -109,6 +110,11 @@ struct ss_ctx {
     std::vector<int32_t> h_oct, h_midx;
     std::vector<uint16_t> h_md1;
 
+    /* SENDSLAM_TRACK_TIMING=1: host seconds of the pose step, printed at ss_destroy (match = enqueue + wait for the device match,
+     * geometry = sst_tracker::step, keep = copies of the descriptors the next frame matches against) */
+    bool track_timing = false;
+    double t_match = 0, t_geom = 0, t_keep = 0;
+    int64_t n_tracked = 0;
     bool profile = false;
     std::vector<stage_rec> stages;
     std::vector<hipEvent_t> event_pool;
@@ -444,6 +450,7 @@ int ss_create(int device_ordinal, const ss_orb_params *params, ss_ctx **out)
     c->device = device_ordinal;
     c->params = p;
     if (const char *e = getenv("SENDSLAM_FORCE_INGEST")) c->force_ingest = atoi(e) != 0;
+    if (const char *e = getenv("SENDSLAM_TRACK_TIMING")) c->track_timing = atoi(e) != 0;
     if (const char *e = getenv("SENDSLAM_MATCH_PACKED")) c->no_desc_x = atoi(e) != 0;
 #ifdef SS_TIMING_KNOBS
     if (const char *e = getenv("SENDSLAM_SKIP_STAGES")) c->skip_stages = atoi(e);
@@ -463,6 +470,9 @@ int ss_destroy(ss_ctx *c)
     if (!c) return SS_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->track_timing && c->n_tracked)
+        fprintf(stderr, "ss_track timing over %lld frames: match %.3f ms, geometry %.3f ms, keep %.3f ms per frame\n", (long long)c->n_tracked,
+                1e3 * c->t_match / c->n_tracked, 1e3 * c->t_geom / c->n_tracked, 1e3 * c->t_keep / c->n_tracked);
     collect_events(c);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     free_geometry_buffers(c);
@@ -800,6 +810,7 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
     }
     int rc;
     const int want = tr.want_match();
+    const auto tm0 = std::chrono::steady_clock::now();
     if (want != SST_MATCH_NONE && n > 0) {
         const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : c->d_prev_desc;
         const uint8_t *train_x = want == SST_MATCH_REF ? c->d_ref_desc_x : c->d_prev_desc_x;
@@ -817,7 +828,22 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     sst_pose_out po;
+    const auto tg0 = std::chrono::steady_clock::now();
     const int keep = tr.step(n, c->h_xy.data(), c->h_oct.data(), c->h_midx.data(), c->h_md1.data(), po);
+    const auto tk0 = std::chrono::steady_clock::now();
+    struct timing_guard {
+        ss_ctx *c;
+        std::chrono::steady_clock::time_point a, b, d;
+        ~timing_guard()
+        {
+            if (!c->track_timing) return;
+            const auto e = std::chrono::steady_clock::now();
+            c->t_match += std::chrono::duration<double>(b - a).count();
+            c->t_geom += std::chrono::duration<double>(d - b).count();
+            c->t_keep += std::chrono::duration<double>(e - d).count();
+            c->n_tracked++;
+        }
+    } tguard{c, tm0, tg0, tk0};
     if (keep != SST_KEEP_NONE && n > 0) {
         uint8_t *&dst = keep == SST_KEEP_AS_REF ? c->d_ref_desc : c->d_prev_desc;
         size_t &dst_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_bytes : c->d_prev_desc_bytes;

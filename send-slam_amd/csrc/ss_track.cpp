@@ -8,8 +8,10 @@
 #include "ss_track.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 namespace {
 
@@ -425,20 +427,26 @@ int pick_hypothesis(const sst_camera &c, int n_hyp, const double (*Rs)[9], const
 {
     int best = -1, best_good = 0, second_good = 0, n_similar = 0;
     double best_parallax = -1;
-    std::vector<double> p3d, best_p3d;
-    std::vector<uint8_t> good, best_flags;
+    /* the hypotheses are checked side by side (each triangulates every inlier): one thread per hypothesis, then the
+     * sequential choice over their results in hypothesis order */
+    std::vector<std::vector<double>> p3ds((size_t)n_hyp);
+    std::vector<std::vector<uint8_t>> flags((size_t)n_hyp);
     std::vector<int> goods((size_t)n_hyp);
+    std::vector<double> parallaxes((size_t)n_hyp, 0.0);
+    {
+        std::vector<std::thread> th;
+        auto run = [&](int k) { goods[(size_t)k] = check_rt(c, Rs[k], ts[k], n, x1, x2, inl, 4.0, p3ds[(size_t)k], flags[(size_t)k], parallaxes[(size_t)k]); };
+        for (int k = 1; k < n_hyp; k++) th.emplace_back(run, k);
+        run(0);
+        for (auto &t_ : th) t_.join();
+    }
     for (int k = 0; k < n_hyp; k++) {
-        double parallax;
-        const int g = check_rt(c, Rs[k], ts[k], n, x1, x2, inl, 4.0, p3d, good, parallax);
-        goods[k] = g;
+        const int g = goods[(size_t)k];
         if (g > best_good) {
             second_good = best_good;
             best_good = g;
             best = k;
-            best_parallax = parallax;
-            best_p3d = p3d;
-            best_flags = good;
+            best_parallax = parallaxes[(size_t)k];
         } else if (g > second_good) {
             second_good = g;
         }
@@ -452,8 +460,8 @@ int pick_hypothesis(const sst_camera &c, int n_hyp, const double (*Rs)[9], const
     }
     memcpy(R, Rs[best], sizeof(double) * 9);
     memcpy(t, ts[best], sizeof(double) * 3);
-    triangulated = best_flags;
-    pts3d = best_p3d;
+    triangulated = std::move(flags[(size_t)best]);
+    pts3d = std::move(p3ds[(size_t)best]);
     int cnt = 0;
     for (uint8_t b : triangulated) cnt += b;
     return cnt;
@@ -475,40 +483,82 @@ int sst_two_view(const sst_camera &c, int n, const double *x1, const double *x2,
     mat3_t(T2, T2t);
     if (!inv3_full(T2, T2inv)) return 0;
 
-    /* FindHomography and FindFundamental on the same 200 minimal sets (ORB-SLAM3 runs them side by side) */
+    /* FindHomography and FindFundamental on the same 200 minimal sets, side by side on threads as ORB-SLAM3 runs them
+     * (Initializer: threadH / threadF): the sets are drawn first, so the outcome does not depend on the threads.  An initialisation attempt is by far the most expensive frame
+     * of a connection (2 x 200 models scored on every match). */
     lcg rng{0x9E3779B97F4A7C15ull};
     std::vector<int> avail((size_t)n);
-    std::vector<uint8_t> inl, best_inl_f, best_inl_h;
-    double best_sf = -1, best_sh = -1, best_F[9] = {0}, best_H[9] = {0};
+    std::vector<std::array<int, 8>> sets(200);
     for (int it = 0; it < 200; it++) {
         for (int i = 0; i < n; i++) avail[i] = i;
-        int idx[8], na = n;
+        int na = n;
         for (int j = 0; j < 8; j++) {
             const int r = (int)rng.next((uint32_t)na);
-            idx[j] = avail[r];
+            sets[(size_t)it][(size_t)j] = avail[r];
             avail[r] = avail[na - 1];
             na--;
         }
-        double Mn[9], tmp[9], M[9], Minv[9];
-        compute_h21(n1.data(), n2.data(), idx, Mn);
-        mat3_mul(T2inv, Mn, tmp);
-        mat3_mul(tmp, T1, M);
-        if (inv3_full(M, Minv)) {
-            const double sh = check_homography(M, Minv, n, x1, x2, inl);
-            if (sh > best_sh) {
-                best_sh = sh;
-                best_inl_h = inl;
-                memcpy(best_H, M, sizeof(M));
+    }
+    /* each model's 200 hypotheses are dealt round-robin to SST_RANSAC_THREADS threads; a thread keeps its best (highest score,
+     * first iteration on a tie), the bests are folded with the same rule: the winner is the one the sequential loop keeps */
+    struct part_best {
+        double score = -1;
+        int it = 1 << 30;
+        double M[9] = {0};
+        std::vector<uint8_t> inl;
+    };
+    constexpr int NT = SST_RANSAC_THREADS;
+    part_best ph[NT], pf[NT];
+    auto fit_part = [&](bool homography, int k) {
+        part_best &b = homography ? ph[k] : pf[k];
+        std::vector<uint8_t> inl;
+        for (int it = k; it < 200; it += NT) {
+            double Mn[9], tmp[9], M[9], Minv[9];
+            double sc;
+            if (homography) {
+                compute_h21(n1.data(), n2.data(), sets[(size_t)it].data(), Mn);
+                mat3_mul(T2inv, Mn, tmp);
+                mat3_mul(tmp, T1, M);
+                if (!inv3_full(M, Minv)) continue;
+                sc = check_homography(M, Minv, n, x1, x2, inl);
+            } else {
+                compute_f21(n1.data(), n2.data(), sets[(size_t)it].data(), Mn);
+                mat3_mul(T2t, Mn, tmp);
+                mat3_mul(tmp, T1, M);
+                sc = check_fundamental(M, n, x1, x2, inl);
+            }
+            if (sc > b.score) {
+                b.score = sc;
+                b.it = it;
+                b.inl = inl;
+                memcpy(b.M, M, sizeof(M));
             }
         }
-        compute_f21(n1.data(), n2.data(), idx, Mn);
-        mat3_mul(T2t, Mn, tmp);
-        mat3_mul(tmp, T1, M);
-        const double sf = check_fundamental(M, n, x1, x2, inl);
-        if (sf > best_sf) {
-            best_sf = sf;
-            best_inl_f = inl;
-            memcpy(best_F, M, sizeof(M));
+    };
+    {
+        std::thread th[2 * NT - 1];
+        for (int k = 0; k < NT; k++) th[k] = std::thread(fit_part, true, k);
+        for (int k = 1; k < NT; k++) th[NT + k - 1] = std::thread(fit_part, false, k);
+        fit_part(false, 0);
+        for (auto &t_ : th) t_.join();
+    }
+    std::vector<uint8_t> best_inl_f, best_inl_h;
+    double best_sf = -1, best_sh = -1, best_F[9] = {0}, best_H[9] = {0};
+    {
+        int wh = -1, wf = -1;
+        for (int k = 0; k < NT; k++) {
+            if (ph[k].score > -1 && (wh < 0 || ph[k].score > ph[wh].score || (ph[k].score == ph[wh].score && ph[k].it < ph[wh].it))) wh = k;
+            if (pf[k].score > -1 && (wf < 0 || pf[k].score > pf[wf].score || (pf[k].score == pf[wf].score && pf[k].it < pf[wf].it))) wf = k;
+        }
+        if (wh >= 0) {
+            best_sh = ph[wh].score;
+            best_inl_h = std::move(ph[wh].inl);
+            memcpy(best_H, ph[wh].M, sizeof(best_H));
+        }
+        if (wf >= 0) {
+            best_sf = pf[wf].score;
+            best_inl_f = std::move(pf[wf].inl);
+            memcpy(best_F, pf[wf].M, sizeof(best_F));
         }
     }
     const double K[9] = {c.fx, 0, c.cx, 0, c.fy, c.cy, 0, 0, 1};

@@ -92,6 +92,10 @@ struct sst_pose_out {
 enum { SST_MATCH_NONE = 0, SST_MATCH_REF = 1, SST_MATCH_PREV = 2 };
 /* sst_pose_only: a Gauss-Newton round ends when no component of the se(3) step exceeds this */
 #define SST_POSE_STEP_EPS 1e-10
+/* sst_two_view: threads per model for the 200 RANSAC hypotheses (results do not depend on it) */
+#ifndef SST_RANSAC_THREADS
+#define SST_RANSAC_THREADS 4
+#endif
 enum { SST_KEEP_NONE = 0, SST_KEEP_AS_REF = 1, SST_KEEP_AS_PREV = 2 };
 
 struct sst_tracker {
