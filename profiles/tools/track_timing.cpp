@@ -1,6 +1,6 @@
 // Host-side cost of the pose step (sst_tracker::step, csrc/ss_track.cpp) on a synthetic track: n points in front of a camera that
 // moves sideways; every frame sees all points (identity matches, Hamming distance 10), octaves 0..7.  Prints ms per frame in
-// tracking state OK.  Build: g++ -O2 -std=c++17 -I include -o /tmp/track_timing profiles/tools/track_timing.cpp send-slam_amd/csrc/ss_track.cpp
+// tracking state OK.  Build: g++ -O2 -std=c++17 -pthread [-DSST_PHASE_TIMING] -I include -o /tmp/track_timing profiles/tools/track_timing.cpp send-slam_amd/csrc/ss_track.cpp
 #include <chrono>
 #include <cstdio>
 #include <random>
@@ -40,8 +40,13 @@ int main(int argc, char **argv)
         tr.step(n, xy.data(), oct.data(), idx.data(), d1.data(), o);
         const double ms = std::chrono::duration_cast<std::chrono::duration<double, std::milli>>(std::chrono::steady_clock::now() - t0).count();
         if (o.state == 2 && f > 2) { total += ms; ok++; }
-        if (f < 4 || f == frames - 1) printf("frame %d state %d matches %d inliers %d map %d  %.3f ms\n", f, o.state, o.n_matches, o.n_inliers, o.n_map_points, ms);
+        if (f < 4 || f % 20 == 0 || f == frames - 1) printf("frame %d state %d matches %d inliers %d map %d  %.3f ms\n", f, o.state, o.n_matches, o.n_inliers, o.n_map_points, ms);
     }
     printf("n %d: %.3f ms per frame in state OK (%d frames)\n", n, ok ? total / ok : 0.0, ok);
+#ifdef SST_PHASE_TIMING
+    extern double sst_phase_ms[8];
+    static const char *names[6] = {"undistort + arrays", "unique matches", "projection gate", "pose-only", "new points", "history + hand-over"};
+    for (int k = 0; k < 6; k++) printf("  %-20s %.3f ms per frame (all %d frames)\n", names[k], sst_phase_ms[k] / frames, frames);
+#endif
     return 0;
 }

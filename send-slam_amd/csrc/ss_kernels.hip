@@ -16,10 +16,10 @@
  *   K5/K6b k_orient_describe   IC_Angle + fastAtan2, steered rBRIEF (4 x __ballot -> 256 bits)
  *   K7  k_match_mfma_x / k_match_mfma / k_match / k_match_stream / k_match_merge*   Hamming best / second best + ratio test
  *
- * Integer / byte work throughout.  The one contraction on the path, the Hamming distance of K7, runs on
- * the matrix cores as an exact +-1 dot product (FP4 operands in k_match_mfma_x, i8 in k_match_mfma; DESIGN.md
- * section 7); nothing else is reshaped into a GEMM (a matrix-pipe form of the blur's horizontal pass exists as a
- * measured-slower variant, FT_BLUR_MFMA).  Every kernel takes the batch slot in blockIdx.y or .z so one launch covers a
+ * Integer / byte work throughout.  Two contractions on the path run on the matrix cores, both exact: the Hamming
+ * distance of K7 as a +-1 dot product (FP4 operands in k_match_mfma_x, i8 in k_match_mfma) and
+ * the 7 x 7 Gaussian of K6a as two band-matrix products of 16 x 16 x 32 int8 tiles inside k_fast_score (FT_BLUR_MFMA;
+ * the vector-pipe form is a compile-time switch).  Nothing else is reshaped into a GEMM.  Every kernel takes the batch slot in blockIdx.y or .z so one launch covers a
  * batch of frames.  Level 0 of the pyramid is read IN PLACE from the caller's buffer when that is a
  * 1-channel image with 16-byte aligned rows (lvl0 != NULL below); otherwise k_ingest writes it into the
  * pyramid block first.
@@ -443,33 +443,49 @@ __global__ __launch_bounds__(256) void k_resize_pair(uint8_t *__restrict__ pyr, 
 /* of survivors (low half, = bucket slot allocator) and of those >= iniTh (high half).      */
 /* ------------------------------------------------------------------------------------ */
 #ifndef FT_BLUR_MFMA
-/* 1: the horizontal Gaussian on the matrix pipe.  Bit-exact and 4 % fewer vector instructions in k_fast_score, but measured
- * SLOWER where it counts: alone 0.336 vs 0.337 ms per 64 frames, four batches in flight 100.3 k vs 101.8 k frames/s (the
- * 128 cycles of the two MFMAs sit in every wave's critical path and the pipe is shared with the matcher).  Kept as the
- * record of that experiment (profiles/tools/build_variant.sh mfmah -DFT_BLUR_MFMA=1). */
-#define FT_BLUR_MFMA 0
+/* 2 (default): both passes of the Gaussian on the matrix pipe (below).  0: on the vector pipe (v_dot4_u32_u8 rows into LDS,
+ * v_dot2_u32_u16 columns): 6 % more vector instructions in k_fast_score, 0.3036 against 0.2896 ms per 64 frames alone, 116.9 k
+ * against 118.4 k frames/s with four batches in flight (profiles/tools/build_variant.sh valub -DFT_BLUR_MFMA=0).  An earlier
+ * form that put only the horizontal pass on the matrix pipe and handed the sums over through LDS measured slower than the
+ * vector form. */
+#define FT_BLUR_MFMA 2
 #endif
-#if FT_BLUR_MFMA
-/* K6a on the matrix pipe: the 7-tap horizontal Gaussian of 32 rows x 32 columns is two v_mfma_i32_32x32x32_i8 (k-steps) of
- * the staged bytes -- A: row i, 64 bytes from pixel x0 - 8 + 32 N on, as int8 = pixel - 128 -- with a constant band
- * matrix, B[k][n] = tap k - n - 5 of output column n (byte k of that window is pixel x0 - 8 + 32 N + k, output
- * column n is pixel x0 + 32 N + n).  Lane (n, half) of either operand carries k = 32 s + 16 half .. + 15 in k-step s.
- * The taps sum to 256, so D = (8.8 fixed-point sum) - 32768: exactly the int16 the vertical pass reads (v_dot2_i32_i16),
- * which adds the 256 * 32768 back through its accumulator constant. */
-struct blur_band { uint32_t w[2][64][4]; };
-constexpr blur_band make_blur_band()
+#if FT_BLUR_MFMA == 2
+/* 2: BOTH passes of K6a on the matrix pipe, the sums of the first handed to the second in registers (no LDS in between).
+ * A wave takes 16 columns of the tile and all 32 rows; v_mfma_i32_16x16x32_i8 throughout (lane = (index & 15, group g = lane >> 4),
+ * operand bytes k = 8 g .. 8 g + 7; result registers r = rows 4 g + r of the lane's column).
+ *   Horizontal: D1[row][col] = sum_k A[row][k] Bh[k][col] for three blocks of 16 staged rows (blur rows rho = 16 mb + 4 g + r);
+ *     A = staged bytes 16 w + 8 + k of the row, as int8 = pixel - 128; Bh[k][j] = tap k - j - 5: a constant band.  D1 = the
+ *     8.8 fixed-point row sum less 32768: fits int16.
+ *   Vertical, transposed so that a lane ends up with four adjacent pixels of one row: D2[col][out row] = sum_k H[col][k]
+ *     Bv[k][out row], H = D1 as the A operand -- the layouts agree, a lane holds rows of ITS column in both -- once for the
+ *     high bytes of the sums and once for the low bytes (xor 0x80: a signed digit, + 128): out rows 16 nb + n read blur rows
+ *     16 nb + n .. + 6, which live in the row blocks nb (operand bytes 0-3) and nb + 1 (bytes 4-7); Bv[k][n] = tap rho - n of
+ *     the byte's row rho = 4 g + s (s < 4) or 16 + 4 g + s - 4.  Contraction indices are free to permute: that is all the
+ *     'transposition' costs.  sum = 256 * (high part) + (low part) + 256 * (32768 + 128); + 2^15 >> 16 as cv::GaussianBlur. */
+struct blur_frag { uint32_t w[64][2]; };
+constexpr int blur_tap(int t) { return t == 0 || t == 6 ? SS_GAUSS_K0 : t == 1 || t == 5 ? SS_GAUSS_K1 : t == 2 || t == 4 ? SS_GAUSS_K2 : t == 3 ? SS_GAUSS_K3 : 0; }
+constexpr blur_frag make_blur_h()
 {
-    blur_band t{};
-    constexpr int taps[7] = {SS_GAUSS_K0, SS_GAUSS_K1, SS_GAUSS_K2, SS_GAUSS_K3, SS_GAUSS_K2, SS_GAUSS_K1, SS_GAUSS_K0};
-    for (int st = 0; st < 2; st++)
-        for (int lane = 0; lane < 64; lane++)
-            for (int b = 0; b < 16; b++) {
-                const int n = lane & 31, k = 32 * st + 16 * (lane >> 5) + b, t7 = k - n - 5;
-                if (t7 >= 0 && t7 < 7) t.w[st][lane][b >> 2] |= (uint32_t)taps[t7] << (8 * (b & 3));
-            }
-    return t;
+    blur_frag f{};
+    for (int lane = 0; lane < 64; lane++)
+        for (int b = 0; b < 8; b++) {
+            const int j = lane & 15, k = 8 * (lane >> 4) + b;
+            f.w[lane][b >> 2] |= (uint32_t)blur_tap(k - j - 5) << (8 * (b & 3));
+        }
+    return f;
 }
-__device__ const blur_band g_blur_band = make_blur_band();
+constexpr blur_frag make_blur_v()
+{
+    blur_frag f{};
+    for (int lane = 0; lane < 64; lane++)
+        for (int s = 0; s < 8; s++) {
+            const int n = lane & 15, g = lane >> 4, rho = s < 4 ? 4 * g + s : 16 + 4 * g + (s - 4);
+            f.w[lane][s >> 2] |= (uint32_t)blur_tap(rho - n) << (8 * (s & 3));
+        }
+    return f;
+}
+__device__ const blur_frag g_blur_h = make_blur_h(), g_blur_v = make_blur_v();
 static_assert(SS_GAUSS_K0 * 2 + SS_GAUSS_K1 * 2 + SS_GAUSS_K2 * 2 + SS_GAUSS_K3 == 256 && SS_GAUSS_K3 < 128, "taps: int8, sum 256");
 #endif
 
@@ -513,7 +529,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     /* `score` may be NULL: no later kernel reads the response map (it exists for stage-by-stage tests) */
     /* horizontal Gaussian sums (8 fractional bits, less 32768: int16), packed as (row 2p, row 2p+1) per pixel
      * so the vertical pass is four v_dot2_i32_i16 per output */
+#if FT_BLUR_MFMA != 2
     __shared__ __attribute__((aligned(16))) uint32_t hpair[FT_BLUR_ROWS / 2][SS_TILE_W];
+#endif
     /* + 1 row: the blur's A operand of the last row / last 16 columns reads up to 40 bytes past it (against zero taps) */
     __shared__ __attribute__((aligned(16))) uint32_t lds[FT_ROWS + 1][FT_WORDS];
     /* scores of the tile and of its 1-px ring: row ly + 1, byte lx + 4 (tile pixels dword-aligned) */
@@ -541,6 +559,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
 #define FT_EXP_HOT 1
 #endif
 
+#if FT_BLUR_MFMA == 2
+    /* the blur's two constant operands: requested first, needed last */
+    uint2 bh2 = *(const uint2 *)&g_blur_h.w[threadIdx.x & 63][0], bv2 = *(const uint2 *)&g_blur_v.w[threadIdx.x & 63][0];
+#endif
     if (threadIdx.x == 0) { n_list = 0; n_corner = 0; }
     if (threadIdx.x < SS_TS_HDR) s_kcnt[threadIdx.x] = 0;
     static_assert(((SS_TILE_H2 + 2) * FT_OWORDS) % 4 == 0 && ((SS_TILE_H2 + 2) * FT_OWORDS) / 4 <= FT_THREADS, "out_tile is cleared by one 16-byte store per thread");
@@ -601,6 +623,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
     }
     if (threadIdx.x < SS_TILE_W) xinf[threadIdx.x] = cinf_v;
     else if (threadIdx.x < SS_TILE_W + SS_TILE_H2) yinf[threadIdx.x - SS_TILE_W] = cinf_v;
+#if FT_BLUR_MFMA == 2
+    /* pins the two loads above here, where the block waits for its staging loads anyway (left alone the compiler sinks them
+     * to their first use, and the blur starts with a trip to the cache) */
+    asm volatile("" : "+v"(bh2.x), "+v"(bh2.y), "+v"(bv2.x), "+v"(bv2.y));
+#endif
     __syncthreads();
 
     /* Phase 1, every pixel: the compass test of cv::FAST.  Any 9 contiguous ring pixels contain
@@ -709,45 +736,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         const int x = x0 + lx, y = y0 + ly;
         if (interior || (x >= 3 && x < w - 3 && y >= 3 && y < h - 3)) list[atomicAdd(&n_list, 1)] = (uint16_t)(((ly + 1) << 8) | (lx + 1));
     }
-#if FT_BLUR_MFMA
-    /* K6a horizontal pass on the same staged tile, on the matrix pipe (see g_blur_band): a wave takes 32 rows x 32 columns;
-     * the lane's sixteen sums are eight (row 2p, row 2p + 1) pairs of its column */
-    if (!(FT_SKIP & 2)) {
-        static_assert(SS_TILE_W == 64, "two 32-column blocks");
-        const int lane = lane_id(), wv = rfl((int)(threadIdx.x >> 6));
-        const int n = lane & 31, half = lane >> 5;
-        const v4i band0 = *(const v4i *)&g_blur_band.w[0][lane][0], band1 = *(const v4i *)&g_blur_band.w[1][lane][0];
-        constexpr int M_BLOCKS = (FT_BLUR_ROWS + 31) / 32;
-        for (int blk = wv; blk < 2 * M_BLOCKS; blk += FT_THREADS / 64) { /* wave-uniform */
-            const int m = blk >> 1, nb = blk & 1;
-            const int srow = imin(32 * m + n + 1, FT_ROWS - 1); /* blur row b = staged row b + 1 */
-            const uint8_t *src = tile8 + srow * (FT_WORDS * 4) + (FT_XB - 8) + 32 * nb + 16 * half;
-            const uint2 l0 = *(const uint2 *)src, h0 = *(const uint2 *)(src + 8), l1 = *(const uint2 *)(src + 32), h1 = *(const uint2 *)(src + 40);
-            constexpr uint32_t S = 0x80808080u;
-            const v4i a0 = v4i{(int)(l0.x ^ S), (int)(l0.y ^ S), (int)(h0.x ^ S), (int)(h0.y ^ S)};
-            const v4i a1 = v4i{(int)(l1.x ^ S), (int)(l1.y ^ S), (int)(h1.x ^ S), (int)(h1.y ^ S)};
-            v16i d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, band0, v16i{0}, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, band1, d, 0, 0, 0);
-            /* lane (n, half): d[r] belongs to blur row 32 m + (r & 3) + 8 (r >> 2) + 4 half, column 32 nb + n */
-            uint32_t *dst = &hpair[16 * m + 2 * half][32 * nb + n];
-            if (32 * m + 32 <= FT_BLUR_ROWS) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    dst[(4 * j) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 1], (uint32_t)d[4 * j], 0x05040100u);
-                    dst[(4 * j + 1) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 3], (uint32_t)d[4 * j + 2], 0x05040100u);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (16 * m + 4 * j >= FT_BLUR_ROWS / 2) break; /* wave-uniform: rows past the blur's window */
-                    const int pair = 16 * m + 4 * j + 2 * half;
-                    if (pair < FT_BLUR_ROWS / 2) dst[(4 * j) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 1], (uint32_t)d[4 * j], 0x05040100u);
-                    if (pair + 1 < FT_BLUR_ROWS / 2) dst[(4 * j + 1) * SS_TILE_W] = __builtin_amdgcn_perm((uint32_t)d[4 * j + 3], (uint32_t)d[4 * j + 2], 0x05040100u);
-                }
-            }
-        }
-    }
-#else
+#if FT_BLUR_MFMA == 0
     /* K6a horizontal pass on the same staged tile.  The 7 taps of pixel i of a dword sit at bytes i + 1 .. i + 7 of the
      * three aligned dwords around it: one v_dot4_u32_u8 per dword that holds any of them, against the taps shifted into
      * place (zeros elsewhere) -- 2 + 3 + 3 + 2 products for four pixels, no byte funnels */
@@ -788,6 +777,43 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
      * pairs); + 2^15 >> 16 as cv::GaussianBlur's fixed-point path.  The queue of phase 2 rarely reaches the upper half
      * of the block (a wave per 64 entries): those waves run this pass while the lower half scores, and take the NMS
      * afterwards, while the lower half runs this pass -- the block's critical path loses one of the two. */
+#if FT_BLUR_MFMA == 2
+    auto blur_v = [&]() { /* both passes: see g_blur_h */
+        if (FT_SKIP & 16) return;
+        const int lane = lane_id(), wv = rfl((int)(threadIdx.x >> 6));
+        const int i16 = lane & 15, g = lane >> 4;
+        const long bh = (long)(((uint64_t)bh2.y << 32) | bh2.x), bv = (long)(((uint64_t)bv2.y << 32) | bv2.x);
+        static_assert(SS_TILE_W == 16 * (FT_THREADS / 64) && SS_TILE_H2 == 32, "a wave per 16 columns, two blocks of 16 output rows");
+        uint32_t lo[3], hi[3];
+#pragma unroll
+        for (int mb = 0; mb < 3; mb++) {
+            /* blur row rho = staged row rho + 1; the last block's rows past the window meet zero taps only: any staged row serves */
+            const int srow = mb < 2 ? 1 + 16 * mb + i16 : imin(1 + 32 + i16, FT_ROWS);
+            const uint2 px = *(const uint2 *)(tile8 + srow * (FT_WORDS * 4) + 16 * wv + 8 + 8 * g);
+            const long a = (long)(((uint64_t)(px.y ^ 0x80808080u) << 32) | (px.x ^ 0x80808080u));
+            const v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, bh, v4i{0, 0, 0, 0}, 0, 0, 0);
+            /* the lane's four sums (rows 4 g .. 4 g + 3 of the block): their low bytes in one dword, their high bytes in another */
+            const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)d[1], (uint32_t)d[0], 0x05010400u);
+            const uint32_t t23 = __builtin_amdgcn_perm((uint32_t)d[3], (uint32_t)d[2], 0x05010400u);
+            lo[mb] = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+            hi[mb] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        }
+        constexpr int KC = 256 * (32768 + 128) + 32768;
+        const int col = x0 + 16 * wv + 4 * g;
+#pragma unroll
+        for (int nb = 0; nb < 2; nb++) {
+            const long ah = (long)(((uint64_t)hi[nb + 1] << 32) | hi[nb]), al = (long)(((uint64_t)lo[nb + 1] << 32) | lo[nb]);
+            const v4i e = __builtin_amdgcn_mfma_i32_16x16x32_i8(ah, bv, v4i{0, 0, 0, 0}, 0, 0, 0);
+            const v4i c = v4i{(int)(((uint32_t)e[0] << 8) + (uint32_t)KC), (int)(((uint32_t)e[1] << 8) + (uint32_t)KC),
+                              (int)(((uint32_t)e[2] << 8) + (uint32_t)KC), (int)(((uint32_t)e[3] << 8) + (uint32_t)KC)};
+            const v4i f = __builtin_amdgcn_mfma_i32_16x16x32_i8(al, bv, c, 0, 0, 0);
+            /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24) */
+            const uint32_t out = __builtin_amdgcn_perm((uint32_t)f[1], (uint32_t)f[0], 0x0C0C0602u) | __builtin_amdgcn_perm((uint32_t)f[3], (uint32_t)f[2], 0x06020C0Cu);
+            const int y = y0 + 16 * nb + i16;
+            if (y < h && col < pitch) *(uint32_t *)(blur + fb + (__umul24((uint32_t)y, (uint32_t)pitch) + (uint32_t)col)) = out;
+        }
+    };
+#else
     auto blur_v = [&]() {
         if (FT_SKIP & 16) return;
         constexpr uint32_t KA0 = SS_GAUSS_K0 | (SS_GAUSS_K1 << 16), KA1 = SS_GAUSS_K2 | (SS_GAUSS_K3 << 16);
@@ -799,15 +825,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
         for (int i = 0; i < 4; i++) {
             const uint32_t p0 = hpair[ty][4 * tx + i], p1 = hpair[ty + 1][4 * tx + i];
             const uint32_t p2 = hpair[ty + 2][4 * tx + i], p3 = hpair[ty + 3][4 * tx + i];
-#if FT_BLUR_MFMA
-            /* the sums are stored less 32768 (int16): 256 * 32768 comes back with the rounding constant */
-            constexpr int RND = 32768 + 256 * 32768;
-            va[i] = (uint32_t)dot2_i16(p0, KA0, dot2_i16(p1, KA1, dot2_i16(p2, KA2, dot2_i16(p3, KA3, RND))));
-            vb[i] = (uint32_t)dot2_i16(p0, KB0, dot2_i16(p1, KB1, dot2_i16(p2, KB2, dot2_i16(p3, KB3, RND))));
-#else
             va[i] = dot2_u16(p0, KA0, dot2_u16(p1, KA1, dot2_u16(p2, KA2, dot2_u16(p3, KA3, 32768u))));
             vb[i] = dot2_u16(p0, KB0, dot2_u16(p1, KB1, dot2_u16(p2, KB2, dot2_u16(p3, KB3, 32768u))));
-#endif
         }
         /* (sum + 2^15) >> 16 is byte 2 of each sum (sums stay below 2^24): three v_perm_b32 gather four of them */
         const uint32_t out_a = __builtin_amdgcn_perm(va[1], va[0], 0x0C0C0602u) | __builtin_amdgcn_perm(va[3], va[2], 0x06020C0Cu);
@@ -820,6 +839,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_fast_score(const uint8_t *__rest
             if (ya + 1 < h) *(uint32_t *)(blur + fb + (o + (uint32_t)pitch)) = out_b;
         }
     };
+#endif
     const bool upper_half = threadIdx.x >= FT_THREADS / 2; /* wave-uniform */
     if (upper_half) blur_v();
 

@@ -968,8 +968,20 @@ void unique_matches(int n, int n_train, const int32_t *idx, const uint16_t *d1, 
 
 } // namespace
 
+#ifdef SST_PHASE_TIMING /* profiles/tools/track_timing.cpp: where a tracked frame's host time goes */
+#include <chrono>
+double sst_phase_ms[8];
+#define SST_PHASE(k) do { const auto now_ = std::chrono::steady_clock::now(); \
+        sst_phase_ms[k] += std::chrono::duration_cast<std::chrono::duration<double, std::milli>>(now_ - phase_t0_).count(); phase_t0_ = now_; } while (0)
+#define SST_PHASE_START auto phase_t0_ = std::chrono::steady_clock::now()
+#else
+#define SST_PHASE(k) do { } while (0)
+#define SST_PHASE_START do { } while (0)
+#endif
+
 int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32_t *match_idx, const uint16_t *d1, sst_pose_out &out)
 {
+    SST_PHASE_START;
     sst_frame cur;
     cur.n = n;
     cur.und.resize((size_t)2 * n);
@@ -988,11 +1000,13 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
     auto pw1 = [&](int o) { return o >= 0 && o < 64 ? s1[o] : std::pow(scale_factor, (double)o); };
     auto pw2 = [&](int o) { return o >= 0 && o < 64 ? s2[o] : std::pow(scale_factor, 2.0 * o); };
     const int want = want_match();
+    SST_PHASE(0); /* undistort + frame arrays + tables */
     std::vector<int32_t> m;
     if (want != SST_MATCH_NONE) {
         unique_matches(n, n_train(), match_idx, d1, m);
         for (int i = 0; i < n; i++) out.n_matches += m[i] >= 0;
     }
+    SST_PHASE(1); /* unique matches */
 
     if (want == SST_MATCH_NONE) { /* NO_IMAGES_YET, LOST, or NOT_INITIALIZED without a reference */
         state = 1;
@@ -1102,8 +1116,10 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
         }
         if (qi.size() >= 20) break;
     }
+    SST_PHASE(2); /* search-by-projection gate */
     std::vector<uint8_t> inl;
     const int n_in = sst_pose_only((int)qi.size(), P.data(), obs.data(), w.data(), cam, cur.R, cur.t, inl);
+    SST_PHASE(3); /* pose-only optimisation */
     out.n_inliers = n_in > 0 ? n_in : 0;
     if (n_in < 30) {
         state = 4;
@@ -1151,6 +1167,7 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
             cur.anchor_sigma2[i] = a_s2;
         }
     }
+    SST_PHASE(4); /* new points */
     pose_hist.insert(pose_hist.end(), cur.R, cur.R + 9);
     pose_hist.insert(pose_hist.end(), cur.t, cur.t + 3);
     /* one long-lived process per camera: keep only the poses an anchored track still refers to (and the newest, which the
@@ -1182,5 +1199,6 @@ int sst_tracker::step(int n, const float *xy, const int32_t *octave, const int32
     out.state = 2;
     sst_pose_to_twc(cur.R, cur.t, out.pos, out.quat);
     prev = std::move(cur);
+    SST_PHASE(5); /* history, velocity, hand-over */
     return SST_KEEP_AS_PREV;
 }
