@@ -37,7 +37,9 @@
  *                              queued on the socket are decoded straight into a pinned slot of an ss_pipe (up to
  *                              SENDSLAM_READAHEAD per batch, default 16), extracted as one batch while the next
  *                              ones are received, then tracked in order (ss_track_features): same poses, same
- *                              messages, in the same order as frame-by-frame ss_track (tests/test_wire.py)
+ *                              messages, in the same order as frame-by-frame ss_track (tests/test_wire.py).
+ *                              The pose step and the answers run on a second thread (SENDSLAM_TRACK_THREAD=0: on the
+ *                              receiving one): batch k is tracked while batch k + 1 is received, decoded and submitted
  *   --selftest-pose            print the pose packet for fixed values as hex and exit (golden
  *                              wire bytes, tests/test_wire.py; needs no GPU)
  */
@@ -49,16 +51,21 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
+#include <mutex>
 #include <numeric>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sendslam_orb.h"
@@ -372,7 +379,7 @@ int main(int argc, char **argv)
 
     constexpr size_t kMaxMessageSize = 50 * 1024 * 1024; /* 50 MB safety guard (:412) */
     bool haveCalibration = false;
-    int exitCode = 0;
+    atomic<int> exitCode{0};
     vector<uint8_t> payload, pix;
 
     /* what TrackMonocular's outputs turn into on the wire (:596-616) */
@@ -424,26 +431,44 @@ int main(int argc, char **argv)
     /* A pipe call that fails for a reason other than a bad frame (a HIP error: the GPU or its driver is in trouble) ends
      * the process with a non-zero code, so that the supervisor starts a fresh backend (docker_handler.ex:117-145 stops itself
      * on a dead container for exactly that).  Carrying on would mean polling slots that can never complete. */
-    bool pipeFailed = false;
+    atomic<bool> pipeFailed{false};
     auto pipe_fatal = [&](const char *what) {
         cerr << "GPU pipeline failed (" << what << "): " << ss_pipe_last_error(pipe) << " -- exiting for a supervised restart" << endl;
         pipeFailed = true;
         exitCode = 3;
     };
+    /* Read-ahead runs on two threads: this one receives, decodes and submits; the tracker takes completed batches in
+     * order, runs the pose step and sends the answers.  They share the count of submitted-but-unanswered batches and
+     * their submit times (under qm); everything else has one writer: the pipe's producer calls are made here, its
+     * consumer calls and ss_track_features (ctx) there, and this thread touches ctx only with nothing in flight. */
+    const bool trackThread = readAhead > 1 && env_int("SENDSLAM_TRACK_THREAD", 1) != 0;
+    mutex qm;
+    condition_variable qcv;
+    bool trackerStop = false;
+    long batchesAnswered = 0;
+    auto in_flight = [&]() {
+        lock_guard<mutex> g(qm);
+        return batchesInFlight;
+    };
     /* takes the oldest completed batch (blocking), tracks its frames in order, ships poses; false = the pipe has failed */
-    auto finish_batch = [&]() -> bool {
+    auto finish_batch_now = [&]() -> bool {
         ss_pipe_result r{};
-        if (pipeFailed || batchesInFlight <= 0 || submitTimes.empty()) return false;
+        chrono::steady_clock::time_point submitted;
+        {
+            lock_guard<mutex> g(qm);
+            if (pipeFailed || batchesInFlight <= 0 || submitTimes.empty()) return false;
+            submitted = submitTimes.front();
+        }
         const auto tw = chrono::steady_clock::now();
         const int wrc = ss_pipe_wait(pipe, &r);
         tWait += secs_since(tw);
         if (wrc != SS_OK) {
             pipe_fatal("ss_pipe_wait");
+            lock_guard<mutex> g(qm);
+            qcv.notify_all();
             return false;
         }
-        const double extractShare = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - submitTimes.front()).count() / max(1, r.n_frames);
-        submitTimes.erase(submitTimes.begin());
-        batchesInFlight--;
+        const double extractShare = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - submitted).count() / max(1, r.n_frames);
         for (int i = 0; i < r.n_frames; i++) {
             if (r.status[i] != SS_OK) {
                 cerr << "Frame skipped: extraction failed (status " << r.status[i] << ")" << endl; /* bad frame => log + skip */
@@ -466,7 +491,48 @@ int main(int argc, char **argv)
             trackSeconds.push_back((float)(ttrack + extractShare));
         }
         ss_pipe_release(pipe, r.slot);
+        {
+            lock_guard<mutex> g(qm);
+            submitTimes.erase(submitTimes.begin());
+            batchesInFlight--;
+            batchesAnswered++;
+        }
+        qcv.notify_all();
         return true;
+    };
+    thread tracker;
+    if (trackThread)
+        tracker = thread([&]() {
+            while (true) {
+                {
+                    unique_lock<mutex> l(qm);
+                    qcv.wait(l, [&] { return trackerStop || (batchesInFlight > 0 && !pipeFailed); });
+                    if (trackerStop) return;
+                }
+                finish_batch_now();
+            }
+        });
+    /* joins the tracker on every way out of main (after the loop, or an early return) */
+    struct at_exit {
+        function<void()> f;
+        ~at_exit() { f(); }
+    } stopTracker{[&]() {
+        if (!tracker.joinable()) return;
+        {
+            lock_guard<mutex> g(qm);
+            trackerStop = true;
+        }
+        qcv.notify_all();
+        tracker.join();
+    }};
+    /* one more batch answered (or none left to wait for); false = the pipe has failed or nothing is in flight */
+    auto finish_batch = [&]() -> bool {
+        if (!trackThread) return finish_batch_now();
+        unique_lock<mutex> l(qm);
+        if (pipeFailed || batchesInFlight <= 0) return false;
+        const long seen = batchesAnswered;
+        qcv.wait(l, [&] { return pipeFailed || batchesAnswered != seen; });
+        return !pipeFailed;
     };
     auto submit_open = [&]() {
         if (!pipe || openN == 0) return;
@@ -477,8 +543,12 @@ int main(int argc, char **argv)
         } else if ([&] { const auto t0 = chrono::steady_clock::now(); const int rc = ss_pipe_submit(pipe, openSlot.slot, openN, openCams.data(), openStamps.data()); tSubmit += secs_since(t0); return rc; }() != SS_OK) {
             pipe_fatal("ss_pipe_submit");
         } else {
-            batchesInFlight++;
-            submitTimes.push_back(chrono::steady_clock::now());
+            {
+                lock_guard<mutex> g(qm);
+                batchesInFlight++;
+                submitTimes.push_back(chrono::steady_clock::now());
+            }
+            qcv.notify_all();
         }
         openN = 0;
         openCams.clear();
@@ -487,7 +557,7 @@ int main(int argc, char **argv)
     /* everything received so far is tracked and answered before the caller goes on (other message types, EOF, idle socket) */
     auto drain_pipe = [&]() {
         submit_open();
-        while (pipe && batchesInFlight > 0 && finish_batch()) {}
+        while (pipe && in_flight() > 0 && finish_batch()) {}
     };
     auto destroy_pipe = [&]() {
         if (!pipeFailed) drain_pipe();
@@ -502,7 +572,7 @@ int main(int argc, char **argv)
     cout << "Connection established. Awaiting calibration parameters..." << endl;
 
     while (true) {
-        if (pipe && (openN > 0 || batchesInFlight > 0) && !input_queued()) drain_pipe(); /* idle socket: answer now */
+        if (pipe && (openN > 0 || in_flight() > 0) && !input_queued()) drain_pipe(); /* idle socket: answer now */
         if (pipeFailed) break;
         uint8_t lengthBuffer[4];
         const auto tr0 = chrono::steady_clock::now();
