@@ -21,7 +21,7 @@
  *                              H2D copy / kernels / D2H copy of different batches overlapped, results in
  *                              host memory -- what the copy at :325 + imdecode :546 + TrackMonocular :594
  *                              do one frame at a time; host half slam_handler.ex:59-88
- *   ss_track_features          the pose half of TrackMonocular :594 for a frame whose features a pipe
+ *   ss_track_features[_matched] the pose half of TrackMonocular :594 for a frame whose features a pipe
  *                              extracted (front door read-ahead of queued frames)
  *   ss_match_partial_device /  the local and the cross-shard half of a query against a database
  *   ss_match_fold_device       partitioned over GPUs
@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 4
+#define SS_ABI_VERSION 5
 #define SS_MAX_LEVELS 16
 #define SS_DESC_BYTES 32
 
@@ -239,6 +239,19 @@ int ss_match_partial_expanded_device(ss_ctx *ctx, const void *d_query_x, int n_q
  * match (th 50, ratio 0.9) and geometry as ss_track; frames must arrive in camera order. */
 int ss_track_features(ss_ctx *ctx, int camera_id, double timestamp, const void *d_descriptors,
                       const ss_keypoint *keypoints, int n_keypoints, ss_pose *out);
+
+/* ss_track_features for a caller that has matched the frames of a batch against each other already (ss_pipe match_mode 1,
+ * ss_match_batch_device mode 1, with th 50 and ratio 9 / 10 -- the pose step's own rule): match_idx / match_d1 are host
+ * arrays of n_keypoints entries, this frame's matches against the frame of the PREVIOUS pose-step call on this context
+ * (NULL, NULL: none).  They are used when that frame is the one the tracker is about to match against (tracking, or the
+ * frame right after a new reference); in every other case the tracker runs its own device match, as ss_track_features
+ * does, so the poses are the same either way.  flags: SS_TRACK_DESC_STAYS_VALID = d_descriptors stays valid and unchanged
+ * until the next pose-step call on this context has returned (the rows of a pipe slot that is released after its last
+ * frame): the tracker then refers to them instead of copying them.  With both, a tracked frame costs no device work. */
+#define SS_TRACK_DESC_STAYS_VALID 1
+int ss_track_features_matched(ss_ctx *ctx, int camera_id, double timestamp, const void *d_descriptors,
+                              const ss_keypoint *keypoints, int n_keypoints, const int32_t *match_idx,
+                              const uint16_t *match_d1, int flags, ss_pose *out);
 
 /* ---- a database partitioned over GPUs ------------------------------------
  * A shard reports, per query descriptor, ss_match_part = (best distance, second-best distance, GLOBAL row of the

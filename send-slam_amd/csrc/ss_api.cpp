@@ -114,6 +114,10 @@ struct ss_ctx {
      * geometry = sst_tracker::step, keep = copies of the descriptors the next frame matches against) */
     bool track_timing = false;
     double t_match = 0, t_geom = 0, t_keep = 0;
+    /* calls of the pose step are numbered: which call's frame the tracker holds as its previous / reference frame, and
+     * whether the previous frame's descriptors are still the caller's rows (ss_track_features_matched) */
+    int64_t track_serial = 0, prev_serial = -1, ref_serial = -1;
+    const uint8_t *d_prev_ext = nullptr;
     int64_t n_tracked = 0;
     bool profile = false;
     std::vector<stage_rec> stages;
@@ -507,6 +511,8 @@ int ss_set_calibration(ss_ctx *c, int camera_id, const ss_camera *cam)
     /* the reference rebuilds the whole ORB_SLAM3::System on every calibration message (:491-518): the map, the
      * reference frame and the motion model do not survive it */
     c->tracker.reset();
+    c->prev_serial = c->ref_serial = -1;
+    c->d_prev_ext = nullptr;
     return SS_OK;
 }
 
@@ -784,18 +790,24 @@ int ss_match_pairs_device(ss_ctx *c, const void *d_query, const void *d_n_query,
 /* the pose half of the frame branch: device match against the initial / previous frame's descriptors, then the host
  * geometry (csrc/ss_track.cpp).  d_desc: n rows of 32 bytes in device memory, written on c->stream or complete. */
 static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t *d_desc, const uint8_t *d_desc_x, const ss_keypoint *kps,
-                      int n, ss_pose *out)
+                      int n, ss_pose *out, const int32_t *given_idx = nullptr, const uint16_t *given_d1 = nullptr, int flags = 0)
 {
     /* d_desc_x: the same n rows already expanded (the extraction's desc_x), or NULL: expanded here when the matrix-core matcher
-     * is going to read them (as the query now, or as the next frames' train set) */
+     * is going to read them (as the query now, or as the next frames' train set).
+     * given_idx / given_d1 (ss_track_features_matched): this frame's matches against the frame of the PREVIOUS call, made by
+     * the caller's batch matcher; used when that frame is the one the tracker is about to match against, and then nothing
+     * is enqueued on the device for this frame. */
     const bool use_x = !c->no_desc_x && n > 0;
-    if (use_x && !d_desc_x) {
+    const int64_t serial = ++c->track_serial;
+    auto expanded = [&]() -> int {
+        if (!use_x || d_desc_x) return SS_OK;
         int rcx = grow(c, c->d_qx, c->d_qx_bytes, (size_t)SS_EXPANDED_BYTES(n));
         if (rcx != SS_OK) return rcx;
         stage_timer t(c, "expand", (int64_t)n * (32 + SSK_X_ROW));
         ssk_expand_desc(c->stream, d_desc, n, c->d_qx);
         d_desc_x = c->d_qx;
-    }
+        return SS_OK;
+    };
     sst_tracker &tr = c->tracker;
     tr.cam = sst_camera{c->cam.fx, c->cam.fy, c->cam.cx, c->cam.cy, c->cam.k1, c->cam.k2, c->cam.p1, c->cam.p2};
     tr.scale_factor = c->params.scale_factor;
@@ -811,25 +823,37 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
     int rc;
     const int want = tr.want_match();
     const auto tm0 = std::chrono::steady_clock::now();
+    const int32_t *m_idx = c->h_midx.data();
+    const uint16_t *m_d1 = c->h_md1.data();
     if (want != SST_MATCH_NONE && n > 0) {
-        const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : c->d_prev_desc;
-        const uint8_t *train_x = want == SST_MATCH_REF ? c->d_ref_desc_x : c->d_prev_desc_x;
-        rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n * 8);
-        if (rc != SS_OK) return rc;
-        int32_t *di = (int32_t *)c->d_mout;
-        uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
-        if (use_x && train_x && n >= SSK_MATCH_MFMA_MIN_QUERIES && tr.n_train() > 0) /* both operands are expanded already */
-            rc = match_expanded(c, d_desc_x, n, train_x, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2, d_desc, train);
-        else
-            rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
-        if (rc != SS_OK) return rc;
-        HIP_TRY(c, hipMemcpyAsync(c->h_midx.data(), di, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_md1.data(), dd1, (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int64_t train_serial = want == SST_MATCH_REF ? c->ref_serial : c->prev_serial;
+        if (given_idx && given_d1 && train_serial == serial - 1 && tr.n_train() > 0) {
+            m_idx = given_idx;
+            m_d1 = given_d1;
+        } else {
+            /* the previous frame's descriptors may still be the caller's (SS_TRACK_DESC_STAYS_VALID): packed rows only */
+            const bool prev_ext = want == SST_MATCH_PREV && c->d_prev_ext != nullptr;
+            const uint8_t *train = want == SST_MATCH_REF ? c->d_ref_desc : prev_ext ? c->d_prev_ext : c->d_prev_desc;
+            const uint8_t *train_x = want == SST_MATCH_REF ? c->d_ref_desc_x : prev_ext ? nullptr : c->d_prev_desc_x;
+            rc = grow(c, c->d_mout, c->d_mout_bytes, (size_t)n * 8);
+            if (rc != SS_OK) return rc;
+            int32_t *di = (int32_t *)c->d_mout;
+            uint16_t *dd1 = (uint16_t *)(c->d_mout + (size_t)n * 4), *dd2 = (uint16_t *)(c->d_mout + (size_t)n * 6);
+            if (use_x && train_x && n >= SSK_MATCH_MFMA_MIN_QUERIES && tr.n_train() > 0) { /* both operands are expanded already */
+                rc = expanded();
+                if (rc == SS_OK) rc = match_expanded(c, d_desc_x, n, train_x, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2, d_desc, train);
+            } else {
+                rc = ss_match_device(c, d_desc, n, train, tr.n_train(), SS_TH_LOW, 9, 10, 0, di, dd1, dd2);
+            }
+            if (rc != SS_OK) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->h_midx.data(), di, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_md1.data(), dd1, (size_t)n * 2, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
     }
     sst_pose_out po;
     const auto tg0 = std::chrono::steady_clock::now();
-    const int keep = tr.step(n, c->h_xy.data(), c->h_oct.data(), c->h_midx.data(), c->h_md1.data(), po);
+    const int keep = tr.step(n, c->h_xy.data(), c->h_oct.data(), m_idx, m_d1, po);
     const auto tk0 = std::chrono::steady_clock::now();
     struct timing_guard {
         ss_ctx *c;
@@ -844,13 +868,23 @@ static int track_step(ss_ctx *c, int camera_id, double timestamp, const uint8_t 
             c->n_tracked++;
         }
     } tguard{c, tm0, tg0, tk0};
-    if (keep != SST_KEEP_NONE && n > 0) {
+    if (keep == SST_KEEP_AS_PREV) {
+        c->prev_serial = serial;
+        c->d_prev_ext = nullptr;
+    } else if (keep == SST_KEEP_AS_REF) {
+        c->ref_serial = serial;
+    }
+    if (keep == SST_KEEP_AS_PREV && n > 0 && (flags & SS_TRACK_DESC_STAYS_VALID)) {
+        c->d_prev_ext = d_desc; /* the caller keeps the rows alive until the next call has returned: nothing to copy */
+    } else if (keep != SST_KEEP_NONE && n > 0) {
         uint8_t *&dst = keep == SST_KEEP_AS_REF ? c->d_ref_desc : c->d_prev_desc;
         size_t &dst_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_bytes : c->d_prev_desc_bytes;
         rc = grow(c, dst, dst_bytes, (size_t)n * SS_DESC_BYTES);
         if (rc != SS_OK) return rc;
         HIP_TRY(c, hipMemcpyAsync(dst, d_desc, (size_t)n * SS_DESC_BYTES, hipMemcpyDeviceToDevice, c->stream));
         if (use_x) {
+            rc = expanded();
+            if (rc != SS_OK) return rc;
             uint8_t *&dst_x = keep == SST_KEEP_AS_REF ? c->d_ref_desc_x : c->d_prev_desc_x;
             size_t &dst_x_bytes = keep == SST_KEEP_AS_REF ? c->d_ref_desc_x_bytes : c->d_prev_desc_x_bytes;
             rc = grow(c, dst_x, dst_x_bytes, (size_t)SS_EXPANDED_BYTES(n));
@@ -892,6 +926,19 @@ int ss_track_features(ss_ctx *c, int camera_id, double timestamp, const void *d_
     if (camera_id == 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing camera identifier.");
     if (n_keypoints > 0 && (!d_descriptors || !keypoints)) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features: NULL feature arrays");
     return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, nullptr, keypoints, n_keypoints, out);
+}
+
+int ss_track_features_matched(ss_ctx *c, int camera_id, double timestamp, const void *d_descriptors, const ss_keypoint *keypoints,
+                              int n_keypoints, const int32_t *match_idx, const uint16_t *match_d1, int flags, ss_pose *out)
+{
+    if (!c || !out || n_keypoints < 0) return SS_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (!c->calibrated) return fail(c, SS_ERR_NOT_CALIBRATED, "Received frame before calibration. Ignoring.");
+    if (camera_id == 0) return fail(c, SS_ERR_BAD_FRAME, "Frame message missing camera identifier.");
+    if (n_keypoints > 0 && (!d_descriptors || !keypoints)) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features_matched: NULL feature arrays");
+    if ((match_idx == nullptr) != (match_d1 == nullptr)) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features_matched: match_idx and match_d1 go together");
+    if (flags & ~SS_TRACK_DESC_STAYS_VALID) return fail(c, SS_ERR_INVALID_ARG, "ss_track_features_matched: unknown flag");
+    return track_step(c, camera_id, timestamp, (const uint8_t *)d_descriptors, nullptr, keypoints, n_keypoints, out, match_idx, match_d1, flags);
 }
 
 int ss_expand_descriptors_device(ss_ctx *c, const void *d_packed, int n, void *d_expanded)
@@ -1054,6 +1101,8 @@ int ss_track_reset(ss_ctx *c)
 {
     if (!c) return SS_ERR_INVALID_ARG;
     c->tracker.reset();
+    c->prev_serial = c->ref_serial = -1;
+    c->d_prev_ext = nullptr;
     return SS_OK;
 }
 

@@ -476,9 +476,15 @@ int main(int argc, char **argv)
             }
             const auto t1 = chrono::steady_clock::now();
             ss_pose tracked{};
-            const int rc = ss_track_features(ctx, r.camera_id[i], r.timestamp[i],
-                                             (const uint8_t *)r.d_descriptors + (size_t)i * r.kp_capacity * SS_DESC_BYTES,
-                                             r.keypoints + (size_t)i * r.kp_capacity, r.n_keypoints[i], &tracked);
+            /* the slot's batch matcher has matched frame i against frame i - 1 (match_mode 1): the pose step takes those when
+             * frame i - 1 is the frame it tracked last, and the slot's rows stay put until the slot is released below */
+            const bool haveMatches = r.match_idx && i > 0 && r.status[i - 1] == SS_OK;
+            const int rc = ss_track_features_matched(ctx, r.camera_id[i], r.timestamp[i],
+                                                     (const uint8_t *)r.d_descriptors + (size_t)i * r.kp_capacity * SS_DESC_BYTES,
+                                                     r.keypoints + (size_t)i * r.kp_capacity, r.n_keypoints[i],
+                                                     haveMatches ? r.match_idx + (size_t)i * r.kp_capacity : nullptr,
+                                                     haveMatches ? r.match_d1 + (size_t)i * r.kp_capacity : nullptr,
+                                                     i + 1 < r.n_frames ? SS_TRACK_DESC_STAYS_VALID : 0, &tracked);
             if (rc != SS_OK) {
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl;
                 continue;
@@ -708,7 +714,11 @@ int main(int argc, char **argv)
                 if (!pipe) {
                     ss_pipe_config cfg{};
                     cfg.width = w; cfg.height = h; cfg.channels = ch;
-                    cfg.batch = readAhead; cfg.depth = 3; cfg.match_mode = -1;
+                    cfg.batch = readAhead; cfg.depth = 3;
+                    /* frame b against frame b - 1 inside a batch, by the pose step's own rule: one launch per batch instead of
+                     * one match + two copies + two waits per frame (SENDSLAM_BATCH_MATCH=0: the pose step matches) */
+                    cfg.match_mode = env_int("SENDSLAM_BATCH_MATCH", 1) ? 1 : -1;
+                    cfg.match_th = 50; cfg.ratio_num = 9; cfg.ratio_den = 10;
                     if (ss_pipe_create(device, &params, &pipeCam, &cfg, &pipe) != SS_OK) {
                         cerr << "Frame skipped: " << ss_pipe_last_error(nullptr) << endl;
                         pipe = nullptr;

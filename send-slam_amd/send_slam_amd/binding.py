@@ -16,7 +16,8 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libsendslam_orb.so")
 SS_MAX_LEVELS = 16
 EXPANDED_ROW_BYTES = 128  # one FP4 value (+1 / -1) per descriptor bit
-ABI_VERSION = 4
+ABI_VERSION = 5
+SS_TRACK_DESC_STAYS_VALID = 1
 
 SS_OK = 0
 SS_ERR_INVALID_ARG, SS_ERR_NO_DEVICE, SS_ERR_HIP, SS_ERR_TOO_SMALL = -1, -2, -3, -4
@@ -28,7 +29,7 @@ EXPORTS = ["ss_abi_version", "ss_orb_params_default", "ss_create", "ss_destroy",
            "ss_match_device", "ss_match_batch_device", "ss_track", "ss_track_reset", "ss_synchronize", "ss_get_stream",
            "ss_profile_enable", "ss_profile_reset", "ss_stats", "ss_debug_fetch", "ss_debug_sort",
            "ss_match_pairs_device", "ss_expand_descriptors_device", "ss_match_expanded_device",
-           "ss_match_partial_expanded_device", "ss_track_features", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
+           "ss_match_partial_expanded_device", "ss_track_features", "ss_track_features_matched", "ss_match_partial_device", "ss_match_fold_device", "ss_wait_stream",
            "ss_pipe_create", "ss_pipe_destroy", "ss_pipe_last_error", "ss_pipe_acquire", "ss_pipe_submit",
            "ss_pipe_submit_frames", "ss_pipe_wait", "ss_pipe_poll", "ss_pipe_release", "ss_pipe_in_flight",
            "ss_match_fold_strided_device", "ss_xchg_create", "ss_xchg_destroy", "ss_xchg_last_error", "ss_xchg_status",
@@ -159,6 +160,8 @@ def load():
     lib.ss_match_expanded_device.argtypes = lib.ss_match.argtypes
     lib.ss_match_partial_expanded_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     lib.ss_track_features.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Pose)]
+    lib.ss_track_features_matched.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.POINTER(Pose)]
     lib.ss_match_partial_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]
     lib.ss_match_fold_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
@@ -289,6 +292,23 @@ class OrbContext:
         po = Pose()
         self._check(self._lib.ss_track_features(self._h, int(camera_id), float(timestamp), C.c_void_p(d_desc),
                                                 kps.ctypes.data, len(kps), C.byref(po)))
+        return {"state": po.tracking_state, "camera_id": po.camera_id, "timestamp": po.timestamp,
+                "position": np.array(list(po.position)), "quaternion": np.array(list(po.quaternion)),
+                "n_keypoints": po.n_keypoints, "n_matches": po.n_matches, "n_inliers": po.n_inliers,
+                "n_map_points": po.n_map_points}
+
+    def track_features_matched(self, d_desc: int, kps: np.ndarray, match_idx=None, match_d1=None, desc_stays_valid: bool = False,
+                               camera_id: int = 1, timestamp: float = 0.0) -> dict:
+        """track_features with this frame's matches against the previous call's frame handed in (int32[n], uint16[n] or None)."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        mi = None if match_idx is None else np.ascontiguousarray(match_idx, np.int32)
+        md = None if match_d1 is None else np.ascontiguousarray(match_d1, np.uint16)
+        if mi is not None and (len(mi) < len(kps) or md is None or len(md) < len(kps)):
+            raise ValueError("match arrays shorter than the keypoints")
+        po = Pose()
+        self._check(self._lib.ss_track_features_matched(self._h, int(camera_id), float(timestamp), C.c_void_p(d_desc), kps.ctypes.data, len(kps),
+                                                        None if mi is None else mi.ctypes.data, None if md is None else md.ctypes.data,
+                                                        SS_TRACK_DESC_STAYS_VALID if desc_stays_valid else 0, C.byref(po)))
         return {"state": po.tracking_state, "camera_id": po.camera_id, "timestamp": po.timestamp,
                 "position": np.array(list(po.position)), "quaternion": np.array(list(po.quaternion)),
                 "n_keypoints": po.n_keypoints, "n_matches": po.n_matches, "n_inliers": po.n_inliers,
@@ -477,11 +497,12 @@ class Pipe:
     release(slot)."""
 
     def __init__(self, device: int, width: int, height: int, channels: int = 1, batch: int = 64, depth: int = 4,
-                 match_mode: int = 0, copy_threads: int = 0, cam: Optional[Camera] = None, **params):
+                 match_mode: int = 0, copy_threads: int = 0, cam: Optional[Camera] = None, match_th: int = 0, ratio_num: int = 0,
+                 ratio_den: int = 0, **params):
         self._lib = load()
         self.params = default_params(**params)
         self.cfg = PipeConfig(width=width, height=height, channels=channels, batch=batch, depth=depth,
-                              match_mode=match_mode, copy_threads=copy_threads)
+                              match_mode=match_mode, match_th=match_th, ratio_num=ratio_num, ratio_den=ratio_den, copy_threads=copy_threads)
         h = C.c_void_p()
         rc = self._lib.ss_pipe_create(int(device), C.byref(self.params), C.byref(cam) if cam is not None else None,
                                       C.byref(self.cfg), C.byref(h))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sendslam_orb.h but not exported"
     assert sorted(binding.EXPORTS) == names
-    assert lib.ss_abi_version() == 4
+    assert lib.ss_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -241,6 +241,58 @@ def test_track_features_after_pipe_equals_ss_track():
         assert np.array_equal(g["position"], o["position"]) and np.array_equal(g["quaternion"], o["quaternion"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad_frame", [None, 5])
+def test_track_features_matched_equals_ss_track(bad_frame):
+    """The front door's read-ahead as it runs now: the pipe matches frame b against frame b - 1 of its batch (match_mode 1,
+    the pose step's th 50 / ratio 0.9), ss_track_features_matched takes those matches and refers to the slot's rows instead
+    of copying them -- no device work per tracked frame -- and falls back to its own device match where the handed-in
+    matches are not against the frame it holds (first frame of a batch, the frame after a skipped one, a reference older
+    than one frame).  == ss_track frame by frame, bit for bit.  With a featureless frame in the middle (tracking lost,
+    restart) and with a frame the producer flags bad (skipped by the caller: the next frame's batch matches point at it)."""
+    w, h, seed, nf = 640, 480, 77, 1000
+    sc = synth.scene(seed, w, h)
+    frames = [synth.parallax_frame(seed, w, h, t, sc=sc) for t in range(11)]
+    frames.insert(7, np.full((h, w), 90, np.uint8))  # featureless: lost, then a new reference
+    cam = binding.Camera(type=b"PinHole", fx=500, fy=500, cx=320, cy=240, k1=-0.05, k2=0.01, p1=1e-4, p2=-1e-4,
+                         width=w, height=h, fps=30, rgb=1, th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+    shown = [f for i, f in enumerate(frames) if i != bad_frame]
+    with binding.OrbContext(0, n_features=nf) as ctx:
+        ctx.set_calibration(1, cam)
+        want = [ctx.track(img, 1, t / 30.0) for t, img in enumerate(shown)]
+    got = []
+    B = 4
+    with binding.Pipe(0, w, h, batch=B, depth=3, match_mode=1, match_th=50, ratio_num=9, ratio_den=10, n_features=nf) as pipe, \
+            binding.OrbContext(0, n_features=nf) as trk:
+        trk.set_calibration(1, cam)
+        sent = [None if i == bad_frame else f for i, f in enumerate(frames)]
+        t_of = {}
+        t = 0
+        for i, f in enumerate(sent):
+            if f is not None:
+                t_of[i] = t / 30.0
+                t += 1
+        for b in range(0, len(sent), B):
+            assert pipe.submit_frames(sent[b:b + B], timestamps=[t_of.get(b + i, -1.0) for i in range(len(sent[b:b + B]))])
+        for b in range(0, len(sent), B):
+            r = pipe.wait()
+            for i in range(r["n_frames"]):
+                if r["status"][i] != binding.SS_OK:
+                    continue
+                n = int(r["n_keypoints"][i])
+                d_desc = r["d_descriptors"] + i * r["kp_capacity"] * 32
+                have = i > 0 and r["status"][i - 1] == binding.SS_OK
+                got.append(trk.track_features_matched(d_desc, r["keypoints"][i, :n], r["match_idx"][i, :n] if have else None,
+                                                      r["match_d1"][i, :n] if have else None, desc_stays_valid=i + 1 < r["n_frames"],
+                                                      camera_id=1, timestamp=float(r["timestamp"][i])))
+            pipe.release(r["slot"])
+    assert [g["state"] for g in got] == [o["state"] for o in want] and got[-1]["state"] == 2 and 4 in [g["state"] for g in got]
+    for g, o in zip(got, want):
+        for k in ("n_keypoints", "n_matches", "n_inliers", "n_map_points", "timestamp"):
+            assert g[k] == o[k], k
+        assert np.array_equal(g["position"], o["position"]) and np.array_equal(g["quaternion"], o["quaternion"])
+
+
 @pytest.mark.parametrize("n_parts,nq,n_db", [(2, 150, 4001), (8, 2000, 160000), (3, 5, 70000), (5, 129, 640)])
 def test_partial_and_fold_equal_one_match(oracle, n_parts, nq, n_db):
     """Config 5 on one card: the database cut into contiguous slabs, ss_match_partial_device per slab (8-byte records
