@@ -445,6 +445,12 @@ def two_view_ba(cam: Camera, obs1, obs2, w1, w2, R, t, X, iterations=20):
 
 
 def triangulate(cam: Camera, x1, x2, R1, t1, R2, t2, sigma2_1, sigma2_2):
+    # LocalMapping::CreateNewMapPoints: only pairs whose viewing rays show parallax (0 < cos < 0.9998) are triangulated
+    q1 = R1.T @ np.array([(x1[0] - cam.cx) / cam.fx, (x1[1] - cam.cy) / cam.fy, 1.0])
+    q2 = R2.T @ np.array([(x2[0] - cam.cx) / cam.fx, (x2[1] - cam.cy) / cam.fy, 1.0])
+    cr = float(q1 @ q2) / (np.sqrt(float(q1 @ q1)) * np.sqrt(float(q2 @ q2)))
+    if not (0 < cr < 0.9998):
+        return None
     X = _triangulate_dlt(cam.K, x1, x2, R1, t1, R2, t2)
     if X is None:
         return None
