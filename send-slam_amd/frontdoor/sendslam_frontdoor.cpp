@@ -444,7 +444,7 @@ int main(int argc, char **argv)
     const bool trackThread = readAhead > 1 && env_int("SENDSLAM_TRACK_THREAD", 1) != 0;
     mutex qm;
     condition_variable qcv;
-    bool trackerStop = false;
+    bool trackerStop = false, trackerBusy = false;
     long batchesAnswered = 0;
     auto in_flight = [&]() {
         lock_guard<mutex> g(qm);
@@ -514,8 +514,14 @@ int main(int argc, char **argv)
                     unique_lock<mutex> l(qm);
                     qcv.wait(l, [&] { return trackerStop || (batchesInFlight > 0 && !pipeFailed); });
                     if (trackerStop) return;
+                    trackerBusy = true;
                 }
                 finish_batch_now();
+                {
+                    lock_guard<mutex> g(qm);
+                    trackerBusy = false;
+                }
+                qcv.notify_all();
             }
         });
     /* joins the tracker on every way out of main (after the loop, or an early return) */
@@ -567,6 +573,10 @@ int main(int argc, char **argv)
     };
     auto destroy_pipe = [&]() {
         if (!pipeFailed) drain_pipe();
+        if (trackThread) { /* a failed pipe is not drained: the tracker may still be inside the batch it took before the failure */
+            unique_lock<mutex> l(qm);
+            qcv.wait(l, [&] { return !trackerBusy; });
+        }
         if (pipe) ss_pipe_destroy(pipe);
         pipe = nullptr;
     };
