@@ -1045,8 +1045,8 @@ def main():
 
     # the Hamming-match kernel (k_match_mfma_x) against the two pipes it uses: the distance of a
     # (query, train) pair is a 256-term contraction of FP4 +-1 values on the matrix cores (512 ops, exact in f32), the
-    # best / second-best selection stays on the VALU: per pair one v_med3_u32 and one v_min_u32 (the key IS the
-    # accumulator), priced with the measured instruction costs (profiles/r01_valu_rates.json).
+    # best / second-best selection stays on the VALU: the key IS the accumulator, a lane keeps the two smallest minima of its
+    # groups of four rows (one instruction per pair), priced with the measured instruction costs (profiles/r01_valu_rates.json).
     match_roofline = None
     mk = next((k for k in kernels if k["name"] == "match"), None)
     rpath = os.path.join(ROOT, "profiles", "r01_valu_rates.json")
@@ -1055,7 +1055,9 @@ def main():
         t = mk["isolated_mean_ms"] * 1e-3
         rates = json.load(open(rpath))
         c = rates["cycles_per_wave64_instruction_per_simd"]
-        sel = c["v_med3_u32"] + c["v_min_u32"]
+        # per group of four rows of a lane: v_min3_u32 + v_min_u32 (the group's minimum), v_med3_u32 + v_min_u32 (the two smallest
+        # group minima): four instructions per four pairs
+        sel = (c["v_min3_u32"] + 2 * c["v_min_u32"] + c["v_med3_u32"]) / 4
         simd_cycles_per_s = rates["cus"] * 4 * rates["clock_mhz"] * 1e6
         valu_floor_ms = pairs / 64 * sel / simd_cycles_per_s * 1e3
         mfma_floor_ms = pairs * 512 / FP4_MFMA_PEAK_OPS * 1e3
@@ -1064,8 +1066,9 @@ def main():
                           "kernel_ms": mk["isolated_mean_ms"], "mfma_floor_ms": round(mfma_floor_ms, 4),
                           "valu_select_cycles_per_64_pairs": round(sel, 1), "valu_select_floor_ms": round(valu_floor_ms, 4),
                           "pairs_per_s": float(f"{pairs / t:.4g}"),
-                          "note": "the instruction sustains 7.6e15 op/s on this chip under load (profiles/r02_fp4_probe.txt: 17.6 ns per 32x32x64 "
-                                  "instruction and SIMD), and 5 are issued per 4 needed (the fifth advances the row index)"}
+                          "note": "the instruction sustains 21-24 ns per 32x32x64 instruction and SIMD beside this kernel's other work "
+                                  "(profiles/r03_fp4_rate_probe.txt: ~1.45 GHz under this load), i.e. 5.6-6.4e15 op/s on the chip; four are "
+                                  "issued per 32 x 32 x 256 tile (the row index rides in the constant C input)"}
 
     # the dominant kernel against the resource that bounds it: VALU issue.  Instructions per FRAME from the committed
     # PMC pass (profiles/per_frame_counters.json: SQ_INSTS_VALU of full-batch launches / frames), duration live; peak =
