@@ -5,7 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "send-slam_amd"))
 from send_slam_amd import binding, synth
-w, h, nf = 640, 480, 1250
+w, h, nf = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (640, 480, 1250)
+quiet = len(sys.argv) > 4
 sc = synth.scene(4000, w, h)
 base = [synth.parallax_frame(4000, w, h, t, sc=sc) for t in range(24)]
 order = list(range(24)) + list(range(22, 0, -1))
@@ -15,6 +16,8 @@ with binding.OrbContext(0, n_features=nf) as ctx:
     ctx.set_calibration(1, cam)
     for i in range(100):
         r = ctx.track(base[order[i % len(order)]], 1, 1.0 + i / 30.0)
+        if quiet and r["state"] == 2:
+            continue
         print(i, "content", order[i % len(order)], "state", r["state"], "kp", r["n_keypoints"], "matches", r["n_matches"], "inliers", r["n_inliers"], "map", r["n_map_points"],
               "pos", np.round(r.get("position", [0, 0, 0]), 3) if "position" in r else "")
 # with a -DSST_PHASE_TIMING build of the library (SENDSLAM_LIB=...): the pose step's phases over those frames
