@@ -639,10 +639,13 @@ def bench_frontdoor(n_frames=192, readahead=16):
         # steady state: from the answer of the first read-ahead batch's last frame to the last answer
         k0 = len(warm)
         rate = (n_frames - k0) / (stamps[-1] - stamps[k0 - 1])
-        # windows of `readahead` consecutive frames that were all tracked (state OK): what a connection sustains between the
-        # (far more expensive) initialisation attempts; this short synthetic sequence loses track once per 46 frames
-        win = sorted(readahead / (stamps[i] - stamps[i - readahead]) for i in range(max(k0, readahead), n_frames)
-                     if all(s_ == 2 for s_ in states[i - readahead + 1:i + 1]) and stamps[i] > stamps[i - readahead])
+        # windows of two batches' worth of consecutive frames that were all tracked (state OK): what a connection sustains
+        # between the (far more expensive) initialisation attempts; this short synthetic sequence loses track once per 46
+        # frames.  Two batches, not one: the answers of ONE batch come at the tracker's pace alone, whatever the receiving
+        # thread needs for the next batch.
+        wl = 2 * readahead
+        win = sorted(wl / (stamps[i] - stamps[i - wl]) for i in range(max(k0, wl), n_frames)
+                     if all(s_ == 2 for s_ in states[i - wl + 1:i + 1]) and stamps[i] > stamps[i - wl])
         tline = next((ln for ln in log.splitlines() if ln.startswith("timing:")), "")
         tok = tline.split()
         tm = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)} if tok else {}

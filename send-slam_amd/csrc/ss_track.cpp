@@ -62,13 +62,73 @@ void jacobi_eig(int n, const double *A_in, double *eval, double *V)
     memcpy(V, Vs, sizeof(double) * (size_t)n * n);
 }
 
+/* Smallest eigenvector of a symmetric positive semi-definite n x n matrix (n <= 9, upper triangle read) by inverse
+ * iteration on the slightly shifted matrix (one Cholesky factorisation, two triangular solves per step): the vector the
+ * Jacobi solver returns, up to sign and a few ulp, for a fraction of its cost -- the 400 minimal-set models of an
+ * initialisation attempt and the triangulation of every new point go through here.  false = no convergence (a repeated
+ * smallest eigenvalue: a degenerate minimal set); the caller falls back to the Jacobi solver.  n is a template parameter:
+ * the loops of the two sizes in use (4: triangulation, 9: homography / fundamental matrix) unroll. */
+template <int n> bool smallest_eigvec(const double *M, double *x)
+{
+    double tr = 0;
+    for (int i = 0; i < n; i++) tr += M[i * n + i];
+    const double shift = 1e-13 * tr;
+    if (!(shift > 0)) return false;
+    double L[n * n] = {0}, id[n];
+    for (int j = 0; j < n; j++) { /* M + shift I = L L^T */
+        double d = M[j * n + j] + shift;
+        for (int k = 0; k < j; k++) d -= L[j * n + k] * L[j * n + k];
+        if (!(d > 0)) return false;
+        L[j * n + j] = std::sqrt(d);
+        const double inv = 1.0 / L[j * n + j];
+        id[j] = inv; /* the solves below multiply by the reciprocals: no division inside the iteration */
+        for (int i = j + 1; i < n; i++) {
+            double v = M[j * n + i];
+            for (int k = 0; k < j; k++) v -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = v * inv;
+        }
+    }
+    double v[n], y[n];
+    const double v0 = 1.0 / std::sqrt((double)n);
+    for (int i = 0; i < n; i++) v[i] = v0;
+    for (int it = 0; it < 60; it++) {
+        for (int i = 0; i < n; i++) {
+            double t = v[i];
+            for (int k = 0; k < i; k++) t -= L[i * n + k] * y[k];
+            y[i] = t * id[i];
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double t = y[i];
+            for (int k = i + 1; k < n; k++) t -= L[k * n + i] * y[k];
+            y[i] = t * id[i];
+        }
+        double nrm = 0;
+        for (int i = 0; i < n; i++) nrm += y[i] * y[i];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 0) || !std::isfinite(nrm)) return false;
+        const double inrm = 1.0 / nrm;
+        double diff = 0, dot = 0;
+        for (int i = 0; i < n; i++) { y[i] *= inrm; dot += y[i] * v[i]; }
+        const double sgn = dot < 0 ? -1.0 : 1.0;
+        for (int i = 0; i < n; i++) { const double w = sgn * y[i]; diff = std::max(diff, std::fabs(w - v[i])); v[i] = w; }
+        if (diff < 1e-15 && it > 0) {
+            for (int i = 0; i < n; i++) x[i] = v[i];
+            return true;
+        }
+    }
+    return false;
+}
+
 /* unit null vector (smallest singular vector) of an m x n system, n <= 9 */
 void null_vector(int m, int n, const double *A, double *x)
 {
     double AtA[81] = {0}, ev[9], V[81];
     for (int r = 0; r < m; r++)
         for (int i = 0; i < n; i++)
-            for (int j = 0; j < n; j++) AtA[i * n + j] += A[r * n + i] * A[r * n + j];
+            for (int j = i; j < n; j++) AtA[i * n + j] += A[r * n + i] * A[r * n + j];
+    if (n == 4 ? smallest_eigvec<4>(AtA, x) : n == 9 ? smallest_eigvec<9>(AtA, x) : false) return;
+    for (int i = 1; i < n; i++)
+        for (int j = 0; j < i; j++) AtA[i * n + j] = AtA[j * n + i];
     jacobi_eig(n, AtA, ev, V);
     for (int i = 0; i < n; i++) x[i] = V[i * n + 0];
 }
@@ -228,72 +288,21 @@ double check_homography(const double *H21, const double *H12, int n, const doubl
     return score;
 }
 
-/* Smallest singular vector of a 4 x 4 system by inverse iteration on A^T A (Cholesky of the slightly shifted
- * matrix, iterated to convergence): the same vector the Jacobi solver returns, ~20x cheaper, which matters because a
- * frame triangulates every match that carries no map point yet.  false = did not converge (caller falls back). */
-bool null_vector4(const double *A, double *x)
+/* P = K [R | t], row-major 3 x 4 */
+void projection_matrix(const sst_camera &c, const double R[9], const double t[3], double P[12])
 {
-    double M[16] = {0};
-    for (int r = 0; r < 4; r++)
-        for (int i = 0; i < 4; i++)
-            for (int j = i; j < 4; j++) M[4 * i + j] += A[4 * r + i] * A[4 * r + j];
-    const double shift = 1e-13 * (M[0] + M[5] + M[10] + M[15]);
-    if (!(shift > 0)) return false;
-    double L[16] = {0};
-    for (int j = 0; j < 4; j++) { /* M + shift I = L L^T */
-        double d = M[5 * j] + shift;
-        for (int k = 0; k < j; k++) d -= L[4 * j + k] * L[4 * j + k];
-        if (!(d > 0)) return false;
-        L[5 * j] = std::sqrt(d);
-        for (int i = j + 1; i < 4; i++) {
-            double v = M[4 * j + i];
-            for (int k = 0; k < j; k++) v -= L[4 * i + k] * L[4 * j + k];
-            L[4 * i + j] = v / L[5 * j];
-        }
-    }
-    double v[4] = {0.5, 0.5, 0.5, 0.5};
-    for (int it = 0; it < 60; it++) {
-        double y[4];
-        for (int i = 0; i < 4; i++) {
-            double t = v[i];
-            for (int k = 0; k < i; k++) t -= L[4 * i + k] * y[k];
-            y[i] = t / L[5 * i];
-        }
-        for (int i = 3; i >= 0; i--) {
-            double t = y[i];
-            for (int k = i + 1; k < 4; k++) t -= L[4 * k + i] * y[k];
-            y[i] = t / L[5 * i];
-        }
-        const double nrm = std::sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);
-        if (!(nrm > 0) || !std::isfinite(nrm)) return false;
-        double diff = 0, dot = 0;
-        for (int i = 0; i < 4; i++) { y[i] /= nrm; dot += y[i] * v[i]; }
-        const double sgn = dot < 0 ? -1.0 : 1.0;
-        for (int i = 0; i < 4; i++) { const double w = sgn * y[i]; diff = std::max(diff, std::fabs(w - v[i])); v[i] = w; }
-        if (diff < 1e-15 && it > 0) {
-            for (int i = 0; i < 4; i++) x[i] = v[i];
-            return true;
-        }
-    }
-    return false;
-}
-
-/* linear triangulation with P = K [R | t]; returns false if the homogeneous weight vanishes */
-bool triangulate_dlt(const sst_camera &c, const double x1[2], const double x2[2], const double R1[9], const double t1[3],
-                     const double R2[9], const double t2[3], double X[3])
-{
-    double P1[12], P2[12];
     const double K[9] = {c.fx, 0, c.cx, 0, c.fy, c.cy, 0, 0, 1};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 4; j++) {
-            double a = 0, b = 0;
-            for (int k = 0; k < 3; k++) {
-                a += K[3 * i + k] * (j < 3 ? R1[3 * k + j] : t1[k]);
-                b += K[3 * i + k] * (j < 3 ? R2[3 * k + j] : t2[k]);
-            }
-            P1[4 * i + j] = a;
-            P2[4 * i + j] = b;
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += K[3 * i + k] * (j < 3 ? R[3 * k + j] : t[k]);
+            P[4 * i + j] = a;
         }
+}
+
+/* linear triangulation with the two projection matrices; returns false if the homogeneous weight vanishes */
+bool triangulate_dlt(const double P1[12], const double P2[12], const double x1[2], const double x2[2], double X[3])
+{
     double A[16];
     for (int j = 0; j < 4; j++) {
         A[j] = x1[0] * P1[8 + j] - P1[j];
@@ -302,7 +311,7 @@ bool triangulate_dlt(const sst_camera &c, const double x1[2], const double x2[2]
         A[12 + j] = x2[1] * P2[8 + j] - P2[4 + j];
     }
     double h[4];
-    if (!null_vector4(A, h)) null_vector(4, 4, A, h);
+    null_vector(4, 4, A, h);
     if (h[3] == 0 || !std::isfinite(h[3])) return false;
     X[0] = h[0] / h[3]; X[1] = h[1] / h[3]; X[2] = h[2] / h[3];
     return std::isfinite(X[0]) && std::isfinite(X[1]) && std::isfinite(X[2]);
@@ -318,10 +327,13 @@ int check_rt(const sst_camera &c, const double R[9], const double t[3], int n, c
     good.assign((size_t)n, 0);
     std::vector<double> cosp;
     int n_good = 0;
+    double P1[12], P2[12]; /* the same two for every point */
+    projection_matrix(c, I, z3, P1);
+    projection_matrix(c, R, t, P2);
     for (int i = 0; i < n; i++) {
         if (!inl[i]) continue;
         double X[3];
-        if (!triangulate_dlt(c, x1 + 2 * i, x2 + 2 * i, I, z3, R, t, X)) continue;
+        if (!triangulate_dlt(P1, P2, x1 + 2 * i, x2 + 2 * i, X)) continue;
         const double n2[3] = {X[0] - O2[0], X[1] - O2[1], X[2] - O2[2]};
         const double d1 = std::sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]);
         const double d2 = std::sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
@@ -808,7 +820,10 @@ bool sst_triangulate(const sst_camera &c, const double x1[2], const double x2[2]
                           (std::sqrt(q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2]) * std::sqrt(q2[0] * q2[0] + q2[1] * q2[1] + q2[2] * q2[2]));
         if (!(cr > 0 && cr < 0.9998)) return false;
     }
-    if (!triangulate_dlt(c, x1, x2, R1, t1, R2, t2, X)) return false;
+    double P1[12], P2[12];
+    projection_matrix(c, R1, t1, P1);
+    projection_matrix(c, R2, t2, P2);
+    if (!triangulate_dlt(P1, P2, x1, x2, X)) return false;
     const double a[3] = {R1[0] * X[0] + R1[1] * X[1] + R1[2] * X[2] + t1[0], R1[3] * X[0] + R1[4] * X[1] + R1[5] * X[2] + t1[1],
                          R1[6] * X[0] + R1[7] * X[1] + R1[8] * X[2] + t1[2]};
     const double b[3] = {R2[0] * X[0] + R2[1] * X[1] + R2[2] * X[2] + t2[0], R2[3] * X[0] + R2[4] * X[1] + R2[5] * X[2] + t2[1],

@@ -729,7 +729,12 @@ int main(int argc, char **argv)
                      * one match + two copies + two waits per frame (SENDSLAM_BATCH_MATCH=0: the pose step matches) */
                     cfg.match_mode = env_int("SENDSLAM_BATCH_MATCH", 1) ? 1 : -1;
                     cfg.match_th = 50; cfg.ratio_num = 9; cfg.ratio_den = 10;
-                    if (ss_pipe_create(device, &params, &pipeCam, &cfg, &pipe) != SS_OK) {
+                    /* a P6 raster is R,G,B on the wire and a B,G,R cv::Mat after imdecode (:546), which Camera.RGB then
+                     * labels; the slots keep the wire order (rows copied as they are, no per-pixel swap on this thread) and
+                     * the pipe's gray conversion is told the opposite label: the same weights on the same bytes */
+                    ss_camera slotCam = pipeCam;
+                    if (ch == 3) slotCam.rgb = pipeCam.rgb ? 0 : 1;
+                    if (ss_pipe_create(device, &params, &slotCam, &cfg, &pipe) != SS_OK) {
                         cerr << "Frame skipped: " << ss_pipe_last_error(nullptr) << endl;
                         pipe = nullptr;
                         continue;
@@ -744,7 +749,14 @@ int main(int argc, char **argv)
                     if (pipeFailed) break;
                 }
                 const auto td0 = chrono::steady_clock::now();
-                pnm_copy(packet.imageData + pnmOff, w, h, ch, openSlot.pixels + (size_t)openN * openSlot.frame_stride, (size_t)openSlot.row_stride);
+                {
+                    const size_t row = (size_t)w * ch;
+                    const uint8_t *src = packet.imageData + pnmOff;
+                    uint8_t *dst = openSlot.pixels + (size_t)openN * openSlot.frame_stride;
+                    if ((size_t)openSlot.row_stride == row) memcpy(dst, src, row * h);
+                    else
+                        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * openSlot.row_stride, src + (size_t)y * row, row);
+                }
                 tDecode += secs_since(td0);
                 openCams.push_back(packet.camera_id);
                 openStamps.push_back(packet.timestamp);

@@ -185,15 +185,20 @@ def test_frontdoor_without_gpu_fails_loudly_at_calibration(frontdoor):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra_env", [{"SENDSLAM_READAHEAD": "1"}, {"SENDSLAM_READAHEAD": "4"}], ids=["frame_by_frame", "read_ahead"])
+@pytest.mark.parametrize("extra_env", [{"SENDSLAM_READAHEAD": "1"}, {"SENDSLAM_READAHEAD": "4"},
+                                       {"SENDSLAM_READAHEAD": "4", "SENDSLAM_TRACK_THREAD": "0"},
+                                       {"SENDSLAM_READAHEAD": "4", "SENDSLAM_BATCH_MATCH": "0"}],
+                         ids=["frame_by_frame", "read_ahead", "read_ahead_one_thread", "read_ahead_own_match"])
 def test_frontdoor_end_to_end_frames(frontdoor, oracle, extra_env):
     """Config 1 of BASELINE.json: fake host <-> front door, calibration then frames of a parallax
     sequence.  Every frame goes through ss_track on the GPU; a pose packet is sent exactly for the
     frames whose tracking state is OK (shim :596) and equals the all-CPU pipeline's pose; the optional
     'features' message carries the counts of that pipeline.  read_ahead: the same stream (run_backend sets
     SENDSLAM_NO_PACING=1) with SENDSLAM_READAHEAD=4 instead of 1 -- queued frames are decoded into pinned slots of an ss_pipe, extracted in batches of up
-    to 4 and tracked in order by ss_track_features (the colour frame changes the geometry mid-stream: the pipe is
-    drained and rebuilt): same messages in the same order."""
+    to 4 and tracked in order, on a second thread, by ss_track_features_matched with the matches the slot's batch matcher
+    made (the colour frame changes the geometry mid-stream: the pipe is drained and rebuilt): same messages in the same
+    order.  read_ahead_one_thread: the pose step on the receiving thread; read_ahead_own_match: the pose step matches
+    frame by frame on the device (no batch matches)."""
     import track_ref
     from oracle import vo_oracle as vo
     w, h, seed = 640, 480, 77
