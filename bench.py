@@ -26,10 +26,12 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                          group (SENDSLAM_BENCH_FORCE_DIST=1) and through the C ABI's own exchange (ss_xchg_*)
   roofline               dominant kernel: ALGORITHMIC bytes per launch / HIP-event mean duration on its own stream
   valu_roofline          the same kernel against the resource that binds it (integer VALU issue)
-  match_roofline         the Hamming-match kernel of the metric (2000 x 2000 per frame) against the int8 MFMA peak
+  match_roofline         the Hamming-match kernel of the metric (2000 x 2000 per frame) against the FP4 MFMA peak
   match_stream_roofline  the Hamming-match kernel in the database-streaming regime (1 and 4 queries against 20 M
                          descriptors = 640 MB): achieved HBM GB/s against the 8 TB/s peak -- the north star's
                          ">= 60 % HBM roofline on the Hamming-match kernel"
+  consecutive_frames     the same step with every frame matched against the frame before it in its batch (SURVEY.md 8(d):
+                         "frame t vs t + 1"); two pairs checked against the oracle
   host_pipeline          the same step fed from HOST memory through the pinned ring of the C ABI (ss_pipe_*):
                          frames/s and PCIe GB/s, copies overlapped with the kernels.  Never `value`.
   frontdoor              the literal drop-in: this process plays SlamHandler over TCP + MessagePack + PNM against the front
@@ -952,6 +954,47 @@ def main():
             iso[s_["name"]] = s_["mean_ms"]
         ctx.profile(False)
 
+    # The same step with each frame matched against the frame BEFORE it in its batch (the frames of a set are consecutive time
+    # steps of one scene: SURVEY.md section 8(d) asks for "frame t vs t + 1" beside the self-match), four batches in
+    # flight like the timed region; two pairs checked against the oracle.  Never `value`.
+    consecutive = None
+    if not a.timed_only:
+        def step_prev(i):
+            k = i % n_ctx
+            c, (o_idx, o_d1, o_d2) = ctxs[k], outs[k]
+            last_set[k] = i % n_sets
+            c.extract_batch_device(d_sets[i % n_sets].data_ptr(), B, w, h)
+            c.match_batch_device(1, o_idx.data_ptr(), o_d1.data_ptr(), o_d2.data_ptr())
+        for i in range(n_ctx):
+            step_prev(i)
+        drain()
+        k_prev = 200
+        t1 = time.perf_counter()
+        for i in range(n_ctx, n_ctx + k_prev):
+            step_prev(i)
+        drain()
+        el_prev = time.perf_counter() - t1
+        k0 = (n_ctx + k_prev - 1) % n_ctx  # the context of the last step: its outputs are that step's
+        idx = outs[k0][0].cpu().numpy()
+        n_kp, n_matched, ok_prev = 0, 0, True
+        prev_desc = None
+        for b in range(B):
+            kps_b, desc_b, _ = ctxs[k0].fetch_frame(b)
+            n = len(kps_b)
+            if b >= 1:
+                n_kp += n
+                n_matched += int((idx[b, :n] >= 0).sum())
+                if b <= 2 and not a.no_cpu_baseline:
+                    oidx, _, _ = O.match(desc_b, prev_desc, 50, 9, 10, exclude_self=False)
+                    ok_prev &= bool(np.array_equal(idx[b, :n], oidx))
+            prev_desc = desc_b
+        if not ok_prev:
+            sys.exit("bench.py: frame-to-previous-frame matches differ from the oracle's")
+        consecutive = {"frames_per_s": round(B * k_prev / el_prev, 1), "ms_per_step": round(el_prev / k_prev * 1e3, 4), "steps": k_prev,
+                       "match": "frame b against frame b - 1 of its batch (th 50, ratio 0.9), frame 0 against itself",
+                       "fraction_of_keypoints_matched": round(n_matched / max(n_kp, 1), 4),
+                       "checked_vs_oracle": not a.no_cpu_baseline}
+
     # Latency path of the drop-in boundary (what the NIF / front door call per camera frame):
     # host pixels in, host keypoints + descriptors out, PCIe copies included.  Never `value`.
     lat = []
@@ -1106,7 +1149,7 @@ def main():
         "rounds": len(times), "timed_region_s": round(sum(times), 4), "value_spread": spread, "sustained": sustained,
         "ranks_reported_by_backend": reported, "single_gpu_exchange": single_gpu_exchange,
         "roofline": roofline, "valu_roofline": valu_roofline, "match_roofline": match_roofline,
-        "match_stream_roofline": match_stream, "host_pipeline": host_pipe, "frontdoor": frontdoor, "kernels": kernels, "cpu_baseline": cpu_obj,
+        "match_stream_roofline": match_stream, "consecutive_frames": consecutive, "host_pipeline": host_pipe, "frontdoor": frontdoor, "kernels": kernels, "cpu_baseline": cpu_obj,
         "parity_checked_vs_oracle": parity,
         "parity_note": "oracle = the committed CPU restatement; parity with the real ORB-SLAM3 binary is unpinned (DESIGN.md section 3)",
         "single_frame_host_to_host_ms": None if single_frame_ms is None else round(single_frame_ms, 3),
