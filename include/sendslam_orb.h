@@ -243,9 +243,9 @@ int ss_track_features(ss_ctx *ctx, int camera_id, double timestamp, const void *
 /* ss_track_features for a caller that has matched the frames of a batch against each other already (ss_pipe match_mode 1,
  * ss_match_batch_device mode 1, with th 50 and ratio 9 / 10 -- the pose step's own rule): match_idx / match_d1 are host
  * arrays of n_keypoints entries, this frame's matches against the frame of the PREVIOUS pose-step call on this context
- * (NULL, NULL: none).  They are used when that frame is the one the tracker is about to match against (tracking, or the
- * frame right after a new reference); in every other case the tracker runs its own device match, as ss_track_features
- * does, so the poses are the same either way.  flags: SS_TRACK_DESC_STAYS_VALID = d_descriptors stays valid and unchanged
+ * that returned SS_OK (NULL, NULL: none -- also the thing to pass after a call that failed).  They are used when that
+ * frame is the one the tracker is about to match against (tracking, or the frame right after a new reference); in every
+ * other case the tracker runs its own device match, as ss_track_features does, so the poses are the same either way.  flags: SS_TRACK_DESC_STAYS_VALID = d_descriptors stays valid and unchanged
  * until the next pose-step call on this context has returned (the rows of a pipe slot that is released after its last
  * frame): the tracker then refers to them instead of copying them.  With both, a tracked frame costs no device work. */
 #define SS_TRACK_DESC_STAYS_VALID 1

@@ -469,16 +469,19 @@ int main(int argc, char **argv)
             return false;
         }
         const double extractShare = chrono::duration_cast<chrono::duration<double>>(chrono::steady_clock::now() - submitted).count() / max(1, r.n_frames);
+        bool prevTracked = false; /* frame i - 1 of this batch went through the pose step */
         for (int i = 0; i < r.n_frames; i++) {
             if (r.status[i] != SS_OK) {
                 cerr << "Frame skipped: extraction failed (status " << r.status[i] << ")" << endl; /* bad frame => log + skip */
+                prevTracked = false;
                 continue;
             }
             const auto t1 = chrono::steady_clock::now();
             ss_pose tracked{};
             /* the slot's batch matcher has matched frame i against frame i - 1 (match_mode 1): the pose step takes those when
-             * frame i - 1 is the frame it tracked last, and the slot's rows stay put until the slot is released below */
-            const bool haveMatches = r.match_idx && i > 0 && r.status[i - 1] == SS_OK;
+             * frame i - 1 is the frame it saw last, and the slot's rows stay put until the slot is released below */
+            const bool haveMatches = r.match_idx && prevTracked;
+            prevTracked = false;
             const int rc = ss_track_features_matched(ctx, r.camera_id[i], r.timestamp[i],
                                                      (const uint8_t *)r.d_descriptors + (size_t)i * r.kp_capacity * SS_DESC_BYTES,
                                                      r.keypoints + (size_t)i * r.kp_capacity, r.n_keypoints[i],
@@ -489,6 +492,7 @@ int main(int argc, char **argv)
                 cerr << "Frame skipped: " << ss_last_error(ctx) << endl;
                 continue;
             }
+            prevTracked = true;
             tTrack += secs_since(t1);
             const auto ts1 = chrono::steady_clock::now();
             emit_tracked(tracked, r.camera_id[i], r.timestamp[i]);
