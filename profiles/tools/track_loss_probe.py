@@ -1,5 +1,7 @@
-"""Where does the front door bench's sequence lose track?  Plays bench_frontdoor's 640x480 sequence through ss_track frame by
-frame and prints state / matches / inliers / map points per frame (GPU box)."""
+"""Where does the front door bench's sequence lose track?  Plays bench_frontdoor's sequence through ss_track frame by frame and
+prints state / matches / inliers / map points per frame (GPU box).  args: width height n_features [q = only the frames that are
+not tracked]; PROBE_TURN=k turns the camera around after k frames instead of 24 (the loss comes 41 frames after the
+initialisation whatever the content: DESIGN.md section 9)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +12,9 @@ quiet = len(sys.argv) > 4
 sc = synth.scene(4000, w, h)
 base = [synth.parallax_frame(4000, w, h, t, sc=sc) for t in range(24)]
 order = list(range(24)) + list(range(22, 0, -1))
+if os.environ.get("PROBE_TURN"):  # turn around after PROBE_TURN frames instead of 24
+    k = int(os.environ["PROBE_TURN"])
+    order = list(range(k)) + list(range(k - 2, 0, -1))
 cam = binding.Camera(type=b"PinHole", fx=0.8 * w, fy=0.8 * w, cx=w / 2, cy=h / 2, k1=0, k2=0, p1=0, p2=0, width=w, height=h, fps=30, rgb=1,
                      th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
 with binding.OrbContext(0, n_features=nf) as ctx:
