@@ -159,7 +159,7 @@ def _check_rt(cam, R, t, x1, x2, inl, th2):
     parallax = 0.0
     if n_good > 0:
         cosp.sort()
-        parallax = math.degrees(math.acos(cosp[min(50, len(cosp) - 1)]))
+        parallax = math.degrees(math.acos(min(1.0, max(-1.0, cosp[min(50, len(cosp) - 1)]))))  # rounding can give 1 + 2e-16
     return n_good, p3d, good, parallax
 
 

@@ -355,7 +355,8 @@ int check_rt(const sst_camera &c, const double R[9], const double t[3], int n, c
     if (n_good > 0) {
         std::sort(cosp.begin(), cosp.end());
         const size_t k = std::min<size_t>(50, cosp.size() - 1);
-        parallax = std::acos(cosp[k]) * 180.0 / 3.14159265358979323846;
+        /* a cosine of two nearly parallel rays can round to 1 + 2e-16: acos of that is NaN, and a NaN parallax passes no test */
+        parallax = std::acos(std::min(1.0, std::max(-1.0, cosp[k]))) * 180.0 / 3.14159265358979323846;
     }
     return n_good;
 }
