@@ -309,12 +309,24 @@ def _se3_exp(d):
     return np.eye(3) + A * Wx + B * W2, (np.eye(3) + B * Wx + C * W2) @ v
 
 
+def _orthonormal(R):
+    """The rotation next to R: rows by Gram-Schmidt, the third as a cross product.  The starting pose of pose_only is a
+    product of estimated rotations (constant-velocity prediction R_k R_{k-1}^T R_k), the optimiser only ever multiplies it
+    by exact exponentials, so a deviation from orthonormality S (R = Q (I + S)) is never removed and comes back about
+    three times larger in the next prediction: after 40 frames of tracking the 'rotation' is sheared by 1e-3 and the
+    tracker is lost (Sophus / g2o keep unit quaternions; this is the matrix form's equivalent)."""
+    r0 = R[0] / np.sqrt(R[0] @ R[0])
+    r1 = R[1] - (R[1] @ r0) * r0
+    r1 = r1 / np.sqrt(r1 @ r1)
+    return np.stack([r0, r1, np.cross(r0, r1)])
+
+
 def pose_only(cam: Camera, pts3d, obs, inv_sigma2, R, t):
     """-> (n_inliers, R, t, inlier mask); n_inliers < 0 on failure"""
     P = np.asarray(pts3d, np.float64).reshape(-1, 3)
     obs = np.asarray(obs, np.float64).reshape(-1, 2)
     w0 = np.asarray(inv_sigma2, np.float64)
-    R, t = np.array(R, np.float64), np.array(t, np.float64)
+    R, t = _orthonormal(np.array(R, np.float64)), np.array(t, np.float64)
     n = len(P)
     inl = np.ones(n, bool)
     if n < 3:

@@ -756,6 +756,23 @@ int sst_pose_only(int n, const double *pts3d, const double *obs, const double *i
 {
     const double chi2_th = 5.991, delta = std::sqrt(5.991);
     inlier.assign((size_t)n, 1);
+    {
+        /* The rotation next to R: rows by Gram-Schmidt, the third as a cross product.  The starting pose is a product of
+         * estimated rotations (the constant-velocity prediction R_k R_{k-1}^T R_k) and the steps below only ever multiply it
+         * by exact exponentials, so a deviation S from orthonormality (R = Q (I + S)) is never removed and comes back about
+         * three times larger in the next prediction: 40 frames after an initialisation the "rotation" was sheared by 1e-3
+         * and the tracker lost every sequence there.  (Sophus / g2o carry unit quaternions; this is the matrix form's
+         * equivalent.) */
+        const double n0 = std::sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]);
+        const double r0[3] = {R[0] / n0, R[1] / n0, R[2] / n0};
+        const double d01 = R[3] * r0[0] + R[4] * r0[1] + R[5] * r0[2];
+        double r1[3] = {R[3] - d01 * r0[0], R[4] - d01 * r0[1], R[5] - d01 * r0[2]};
+        const double n1 = std::sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+        for (double &v : r1) v /= n1;
+        const double Ro[9] = {r0[0], r0[1], r0[2], r1[0], r1[1], r1[2],
+                              r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+        memcpy(R, Ro, sizeof(Ro));
+    }
     if (n < 3) return -1;
     int n_in = n;
     std::vector<int> active((size_t)n);
