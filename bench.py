@@ -642,9 +642,8 @@ def bench_frontdoor(n_frames=192, readahead=16):
         k0 = len(warm)
         rate = (n_frames - k0) / (stamps[-1] - stamps[k0 - 1])
         # windows of two batches' worth of consecutive frames that were all tracked (state OK): what a connection sustains
-        # between the (far more expensive) initialisation attempts; this short synthetic sequence loses track once per 46
-        # frames.  Two batches, not one: the answers of ONE batch come at the tracker's pace alone, whatever the receiving
-        # thread needs for the next batch.
+        # away from the (far more expensive) initialisation attempts.  Two batches, not one: the answers of ONE batch come
+        # at the tracker's pace alone, whatever the receiving thread needs for the next batch.
         wl = 2 * readahead
         win = sorted(wl / (stamps[i] - stamps[i - wl]) for i in range(max(k0, wl), n_frames)
                      if all(s_ == 2 for s_ in states[i - wl + 1:i + 1]) and stamps[i] > stamps[i - wl])
