@@ -646,3 +646,26 @@ def test_quadtree_first_pass_overshoot_vs_oracle(oracle):
     okps, odesc, ocounts = oracle.extract(img, oracle.default_params(**kw))
     assert np.array_equal(counts, ocounts) and counts.sum() > 85
     assert kps.tobytes() == okps.tobytes() and np.array_equal(desc, odesc)
+@pytest.mark.gpu
+def test_ss_track_keeps_a_long_back_and_forth_sequence():
+    """ss_track over 150 frames of a camera that goes back and forth over 24 positions (the front door bench's sequence): tracked
+    from the third frame to the last, the same position again every 46 frames.  Regression for the rotation that drifted from
+    orthonormality through the constant-velocity prediction: every sequence used to be lost 41 frames after its
+    initialisation."""
+    w, h, nf = 640, 480, 1250
+    sc = synth.scene(4000, w, h)
+    base = [synth.parallax_frame(4000, w, h, t, sc=sc) for t in range(24)]
+    order = list(range(24)) + list(range(22, 0, -1))
+    cam = binding.Camera(type=b"PinHole", fx=0.8 * w, fy=0.8 * w, cx=w / 2, cy=h / 2, k1=0, k2=0, p1=0, p2=0, width=w, height=h, fps=30,
+                         rgb=1, th_depth=40.0, baseline=0.0, depth_map_factor=1000.0)
+    with binding.OrbContext(0, n_features=nf) as ctx:
+        ctx.set_calibration(1, cam)
+        outs = [ctx.track(base[order[i % len(order)]], 1, 1.0 + i / 30.0) for i in range(150)]
+    states = [o["state"] for o in outs]
+    first_ok = states.index(2)
+    assert first_ok <= 4 and all(s_ == 2 for s_ in states[first_ok:]), "".join(map(str, states))
+    for i in range(first_ok + len(order), 150):
+        assert np.linalg.norm(outs[i]["position"] - outs[i - len(order)]["position"]) < 0.05, i
+        assert abs(float(outs[i]["quaternion"] @ outs[i]["quaternion"]) - 1.0) < 1e-9
+
+
