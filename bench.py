@@ -508,7 +508,7 @@ def bench_host_pipeline(binding, frames_sets, w, h, nf, B, local_rank, depth=4, 
     n_sets = frames_sets.shape[0]
     res = {}
     cores = len(os.sched_getaffinity(0))
-    with binding.Pipe(local_rank, w, h, batch=B, depth=depth, match_mode=0, copy_threads=min(8, max(2, cores // 2)), n_features=nf) as pipe:
+    with binding.Pipe(local_rank, w, h, batch=B, depth=depth, match_mode=0, copy_threads=int(os.environ.get("SENDSLAM_BENCH_COPY_THREADS", min(8, max(2, cores // 2)))), n_features=nf) as pipe:
         kcap = None
 
         def drain_one():
