@@ -44,13 +44,16 @@ def test_world1_exchange_returns_own_block():
 
 
 @pytest.mark.gpu
-def test_two_processes_one_card_configs_4_and_5(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 4])
+def test_processes_on_one_card_configs_4_and_5(tmp_path, oracle, world):
+    """world = 4: four slabs / four peers per message -- the flag and slot indexing beyond two ranks, which is what an 8-GPU node
+    runs and no 2-rank test touches (four processes share the one card; IPC mappings work on the same device)."""
     path = str(tmp_path / "xchg.sock")
-    mp.spawn(multi_worker.run_xchg, args=(2, path, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(multi_worker.run_xchg, args=(world, path, str(tmp_path)), nprocs=world, join=True)
     for k, seed in enumerate((5, 6, 7)):
         q, db = multi_worker.make_db(seed, 4001, 150)
         want = oracle.match(q, db, th=256, ratio_num=10)
-        for r in range(2):
+        for r in range(world):
             z = np.load(os.path.join(str(tmp_path), f"xlc{k}_{r}.npz"))
             assert np.array_equal(z["query"], q), "the broadcast did not deliver rank 0's query"
             assert np.array_equal(z["idx"], want[0]) and np.array_equal(z["d1"], want[1]) and np.array_equal(z["d2"], want[2]), (k, r)
@@ -60,11 +63,12 @@ def test_two_processes_one_card_configs_4_and_5(tmp_path, oracle):
     counts = [np.array([150, 171, 0], np.int32), np.array([171, 128, 192], np.int32)]
     eyes[1][:, :100] = eyes[0][:, :100]
     eyes[1][:, :100, 4] ^= 0x0F
-    for r in range(2):
+    for r in range(world):
         z = np.load(os.path.join(str(tmp_path), f"xst_{r}.npz"))
+        me = r % 2  # rank r holds eye r % 2 and matches it against rank r + 1's
         for b in range(B):
-            nq, nt = counts[r][b], counts[1 - r][b]
-            w = oracle.match(eyes[r][b, :nq], eyes[1 - r][b, :nt])
+            nq, nt = counts[me][b], counts[1 - me][b]
+            w = oracle.match(eyes[me][b, :nq], eyes[1 - me][b, :nt])
             assert np.array_equal(z["idx"][b, :nq], w[0]) and np.array_equal(z["d1"][b, :nq], w[1]) and np.array_equal(z["d2"][b, :nq], w[2]), (r, b)
             assert (z["idx"][b, nq:] == -1).all()
         assert int(np.load(os.path.join(str(tmp_path), f"xmsg_{r}.npz"))["bad"]) == 0
