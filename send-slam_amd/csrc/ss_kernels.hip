@@ -2698,6 +2698,9 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void k_match_mfma_x(const uint8_
                 arow = &tiles[0][0] + (a_base + (uint32_t)rd_off);
                 rd_off = rd_off == (MX_NBUF - 1) * MX_BUF ? 0 : rd_off + MX_BUF;
             }
+#ifdef MX_SETPRIO /* timing experiment: the wave asks for issue priority while its matrix instructions go out */
+            __builtin_amdgcn_s_setprio(MX_SETPRIO);
+#endif
 #pragma unroll
             for (int sstep = 0; sstep < 4; sstep++) {
                 const v4i f = PIPE ? a4[sstep] : *(const v4i *)(arow + 32 * sstep);
@@ -2716,6 +2719,9 @@ __global__ __launch_bounds__(256, PIPE ? 2 : 5) void k_match_mfma_x(const uint8_
                     ac[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[u][sstep], ci, MX_FMT_FP4, MX_FMT_FP4, 0, MX_SCALE_ONE + 12, 0, MX_SCALE_ONE);
                 }
             }
+#ifdef MX_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         auto select_tile = [&](v16f(&ac)[MX_QT]) {
 #if defined(MX_EXP) && MX_EXP == 4 /* timing experiment 4: no selection (one key per tile keeps the MFMAs alive) */
