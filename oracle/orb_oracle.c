@@ -966,6 +966,19 @@ int orc_pnp_pose_only(int n, const double *pts3d, const double *obs, const doubl
                       double cx, double cy, double R[9], double t[3], uint8_t *inlier)
 {
     const double chi2_th = 5.991, delta = sqrt(5.991);
+    {
+        /* the rotation next to R (rows by Gram-Schmidt, the third as a cross product): the steps below only multiply by exact
+         * exponentials and never remove a deviation from orthonormality the caller's prediction brings (vo_oracle._orthonormal) */
+        const double n0 = sqrt(R[0] * R[0] + R[1] * R[1] + R[2] * R[2]);
+        const double r0[3] = {R[0] / n0, R[1] / n0, R[2] / n0};
+        const double d01 = R[3] * r0[0] + R[4] * r0[1] + R[5] * r0[2];
+        double r1[3] = {R[3] - d01 * r0[0], R[4] - d01 * r0[1], R[5] - d01 * r0[2]};
+        const double n1 = sqrt(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+        for (int k = 0; k < 3; k++) r1[k] /= n1;
+        R[0] = r0[0]; R[1] = r0[1]; R[2] = r0[2];
+        R[3] = r1[0]; R[4] = r1[1]; R[5] = r1[2];
+        R[6] = r0[1] * r1[2] - r0[2] * r1[1]; R[7] = r0[2] * r1[0] - r0[0] * r1[2]; R[8] = r0[0] * r1[1] - r0[1] * r1[0];
+    }
     if (n < 3) return -1;
     for (int i = 0; i < n; i++) inlier[i] = 1;
     int n_in = n;
