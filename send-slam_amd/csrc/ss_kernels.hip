@@ -1872,6 +1872,9 @@ __device__ __forceinline__ uint32_t fp4_of_4bits(uint32_t nib)
 #ifndef OD_KP
 #define OD_KP 1 /* measured in the four-context pipeline: 1 -> 93.5-95.4 k frames/s, 2 -> 92.5 k (twice the LDS per block) */
 #endif
+#ifndef OD_SEQ
+#define OD_SEQ 0 /* 1 with OD_KP = 2 or 4: bit-exact, fewer vector instructions, 113.2 k against 117.8 k frames/s in the pipeline */
+#endif
 #ifndef OD_PITCH
 #define OD_PITCH 80
 #endif
@@ -1902,10 +1905,13 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     /* 16-byte pieces: the texture addresser, which takes 64 lane addresses per load instruction whatever their width,
      * was the busiest unit of this kernel with dword loads (TA_BUSY 75 %); a row of the patch is 3 pieces from the
      * 16-byte boundary at or below kx - 15, a row of the window 4 pieces from the one at or below kx - 18 */
-    __shared__ __attribute__((aligned(16))) uint32_t patch_all[4][KP][31 * 12 + 4]; /* + 4: the last row's masked-off tail read */
+    /* OD_SEQ: the KP keypoints of a wave go through ONE patch buffer and ONE window buffer one after the other (their loads
+     * are still issued together and wait in registers): the LDS of KP = 1, the angle / sine / cosine evaluation shared by KP */
+    constexpr int KL = OD_SEQ ? 1 : KP;
+    __shared__ __attribute__((aligned(16))) uint32_t patch_all[4][KL][31 * 12 + 4]; /* + 4: the last row's masked-off tail read */
     /* window rows at an OD_PITCH-byte pitch (>= 64, multiple of 16): at 64 bytes rows r and r + 2 share their banks; at 80 only
      * rows r and r + 8 do, and the byte gathers of the 64 lanes (anywhere in the window) collide less */
-    __shared__ __attribute__((aligned(16))) uint32_t win_all[4][KP][37 * (OD_PITCH / 4)];
+    __shared__ __attribute__((aligned(16))) uint32_t win_all[4][KL][37 * (OD_PITCH / 4)];
     int slot[KP], level[KP], kx[KP], ky[KP], resp[KP], pitch[KP], px0[KP], wx0[KP];
     size_t fb[KP];
     uint2 ref[KP];
@@ -1952,26 +1958,40 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
             wv[k][it] = idx < 37 * 4 ? *(const uint4 *)(b0 + (__umul24((uint32_t)(idx >> 2), (uint32_t)pitch[k]) + 16u * (uint32_t)(idx & 3))) : make_uint4(0, 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int k = 0; k < KP; k++) {
-        uint4 *pl = (uint4 *)&patch_all[threadIdx.x >> 6][k][0], *wl = (uint4 *)&win_all[threadIdx.x >> 6][k][0];
+    auto store_patch = [&](int k) {
+        uint4 *pl = (uint4 *)&patch_all[threadIdx.x >> 6][OD_SEQ ? 0 : k][0];
 #pragma unroll
         for (int it = 0; it < 2; it++)
             if (lane + WAVE * it < 31 * 3) pl[lane + WAVE * it] = pv[k][it];
+    };
+    auto store_window = [&](int k) {
+        uint4 *wl = (uint4 *)&win_all[threadIdx.x >> 6][OD_SEQ ? 0 : k][0];
 #pragma unroll
         for (int it = 0; it < 3; it++)
             if (lane + WAVE * it < 37 * 4) wl[((lane + WAVE * it) >> 2) * (OD_PITCH / 16) + ((lane + WAVE * it) & 3)] = wv[k][it];
+    };
+    if (!OD_SEQ) {
+#pragma unroll
+        for (int k = 0; k < KP; k++) {
+            store_patch(k);
+            store_window(k);
+        }
+        wave_sync();
     }
-    wave_sync();
     int m10[KP], m01[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++) {
+        if (OD_SEQ) {
+            if (k > 0) wave_sync(); /* the reads of the keypoint before are done */
+            store_patch(k);
+            wave_sync();
+        }
         /* the lane's pixels are 16 consecutive bytes of its staged row starting at u0 (the tail masked off): five
          * aligned dwords, four v_alignbyte, then m10 = sum u * I = u0 * sum I + sum k * I_k and m01 = v * sum I as
          * eight v_dot4_u32_u8 -- integer sums, so the order of additions is free */
         const int row = imin(lane & 31, 30); /* lanes 31 and 63 carry zero masks */
         const int sb = (kx[k] - px0[k]) + u0; /* 0 .. 30: byte offset in the staged row */
-        const uint32_t *rw = &patch_all[threadIdx.x >> 6][k][row * 12 + (sb >> 2)];
+        const uint32_t *rw = &patch_all[threadIdx.x >> 6][OD_SEQ ? 0 : k][row * 12 + (sb >> 2)];
         const uint32_t sh = (uint32_t)sb & 3u;
         const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3], w4 = rw[4];
         const uint32_t a0 = __builtin_amdgcn_alignbyte(w1, w0, sh) & icm.x, a1 = __builtin_amdgcn_alignbyte(w2, w1, sh) & icm.y;
@@ -2042,7 +2062,12 @@ __global__ __launch_bounds__(256) void k_orient_describe(const ss_geom *__restri
     int t0[KP][4], t1[KP][4];
 #pragma unroll
     for (int k = 0; k < KP; k++) {
-        const uint8_t *center = (const uint8_t *)&win_all[threadIdx.x >> 6][k][0];
+        if (OD_SEQ) {
+            if (k > 0) wave_sync();
+            store_window(k);
+            wave_sync();
+        }
+        const uint8_t *center = (const uint8_t *)&win_all[threadIdx.x >> 6][OD_SEQ ? 0 : k][0];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             t0[k][q] = center[off0[k][q]];
